@@ -1,0 +1,735 @@
+// Host side of the aclnn-style two-phase C-ABI (see include/*.h): descriptor shim, operand
+// validation, launch planning (the counterpart of the reference's host tiling functions,
+// cent_select_tiling.cpp:11-115 and sparse_paged_fusion_attention_tiling.cc:66-2200) and the
+// stream-ordered launch.  Phase 1 (GetWorkspaceSize) is synchronous host code and copies everything
+// it needs out of the descriptors; phase 2 only enqueues work on the caller's hipStream_t and never
+// synchronises or allocates.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/aclnn_cent_select.h"
+#include "../../include/aclnn_compute_cent.h"
+#include "../../include/aclnn_select_position.h"
+#include "../../include/aclnn_sparse_paged_attention.h"
+#include "../../include/aclnn_sparse_paged_fusion_attention.h"
+#include "spfa_params.h"
+
+struct aclTensor {
+    std::vector<int64_t> dims, strides;
+    int64_t offset = 0;
+    aclDataType dtype = ACL_DT_UNDEFINED;
+    void* data = nullptr;
+};
+struct aclTensorList { std::vector<aclTensor*> items; };
+struct aclIntArray { std::vector<int64_t> v; };
+
+enum OpKind { kOpComputeCent, kOpSelectPosition, kOpCentSelect, kOpAttention, kOpFusion };
+
+struct aclOpExecutor {
+    OpKind op;
+    bool repeatable = false;
+    spfa::CentParams cent{};
+    spfa::SelectParams sel{};
+    spfa::AttnParams attn{};
+    std::vector<long long> act_seq;   // host copy of actualSeqLengths, expanded to B values
+    uint64_t ws_bytes = 0;
+};
+
+namespace {
+
+thread_local std::string g_err;
+thread_local int64_t g_topk = 64;
+thread_local int g_sink_recent = 0;
+thread_local int g_page_cap = 0;
+thread_local int64_t g_page_size = 128;   // PAGESIZE of cent_select.cpp:17 / select_position.cpp:112
+thread_local const long long* g_act_seq_dev = nullptr;   // one-shot, consumed by the next attention plan
+thread_local int64_t g_act_seq_dev_n = 0;
+
+constexpr size_t kMaxLds = 160 * 1024;    // LDS per CU on gfx950
+
+aclnnStatus fail(aclnnStatus code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define REQUIRE(cond, ...)                                            \
+    do {                                                              \
+        if (!(cond)) return fail(ACLNN_ERR_PARAM_INVALID, __VA_ARGS__); \
+    } while (0)
+#define REQUIRE_PTR(p, name)                                                         \
+    do {                                                                             \
+        if ((p) == nullptr) return fail(ACLNN_ERR_PARAM_NULLPTR, "%s must not be NULL", name); \
+    } while (0)
+
+int elem_size(aclDataType t) {
+    switch (t) {
+        case ACL_FLOAT: case ACL_INT32: case ACL_UINT32: return 4;
+        case ACL_FLOAT16: case ACL_BF16: case ACL_INT16: case ACL_UINT16: return 2;
+        case ACL_INT8: case ACL_UINT8: case ACL_BOOL: return 1;
+        case ACL_INT64: case ACL_UINT64: case ACL_DOUBLE: return 8;
+        default: return 0;
+    }
+}
+
+int64_t numel(const aclTensor* t) {
+    int64_t n = 1;
+    for (int64_t d : t->dims) n *= d;
+    return n;
+}
+
+bool is_contiguous(const aclTensor* t) {
+    int64_t expect = 1;
+    for (int i = (int)t->dims.size() - 1; i >= 0; --i) {
+        if (t->dims[i] != 1 && t->strides[i] != expect) return false;
+        expect *= t->dims[i];
+    }
+    return true;
+}
+
+void* data_ptr(const aclTensor* t) { return (char*)t->data + t->offset * elem_size(t->dtype); }
+
+// Optional operands arrive as NULL (the binding maps numel()==0 tensors to NULL, add_custom.cpp:32-35);
+// a descriptor with zero elements is treated the same way.
+bool absent(const aclTensor* t) { return t == nullptr || numel(t) == 0 || t->data == nullptr; }
+
+aclnnStatus check_tensor(const aclTensor* t, const char* name, size_t ndim, aclDataType dtype) {
+    REQUIRE_PTR(t, name);
+    REQUIRE(t->dims.size() == ndim, "%s: expected %zu dims, got %zu", name, ndim, t->dims.size());
+    REQUIRE(t->dtype == dtype, "%s: unexpected dtype %d (expected %d)", name, (int)t->dtype, (int)dtype);
+    REQUIRE(is_contiguous(t), "%s must be contiguous", name);
+    REQUIRE(t->data != nullptr || numel(t) == 0, "%s has no device memory", name);
+    return ACLNN_SUCCESS;
+}
+#define CHECK(expr)                           \
+    do {                                      \
+        aclnnStatus _s = (expr);              \
+        if (_s != ACLNN_SUCCESS) return _s;   \
+    } while (0)
+
+int to_dtype(aclDataType t) {
+    switch (t) {
+        case ACL_FLOAT16: return spfa::kF16;
+        case ACL_BF16: return spfa::kBF16;
+        case ACL_INT8: return spfa::kI8;
+        case ACL_FLOAT: return spfa::kF32;
+        default: return -1;
+    }
+}
+
+int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// q heads of one group that can be scored per pass: keys [rows][Cp] u32 must fit a 64 KiB budget
+int score_rows_per_pass(int G, int Cp, int cap) {
+    int r = (64 * 1024) / (Cp * 4);
+    if (r < 1) r = 1;
+    if (r > cap) r = cap;
+    if (r > G) r = G;
+    return r;
+}
+
+aclnnStatus check_qcent(const aclTensor* query, const aclTensor* l1, int* Hq, int* Hkv, int* D, int* C) {
+    REQUIRE_PTR(query, "query");
+    REQUIRE_PTR(l1, "l1_cent");
+    REQUIRE(query->dtype == ACL_FLOAT16 || query->dtype == ACL_BF16, "query must be float16 or bfloat16");
+    REQUIRE(l1->dtype == query->dtype, "l1_cent dtype must match query (cent_select_def.cpp:12-21)");
+    REQUIRE(l1->dims.size() == 3, "l1_cent must be [Hkv, C, D]");
+    REQUIRE(is_contiguous(query) && is_contiguous(l1), "query / l1_cent must be contiguous");
+    *Hkv = (int)l1->dims[0];
+    *C = (int)l1->dims[1];
+    *D = (int)l1->dims[2];
+    REQUIRE(*Hkv > 0 && *C > 0, "l1_cent is empty");
+    REQUIRE(*D % 32 == 0 && *D >= 32 && *D <= 256, "head dim %d: must be a multiple of 32 in [32, 256]", *D);
+    REQUIRE(*C <= 16384, "cluster count %d exceeds 16384", *C);
+    (void)Hq;
+    return ACLNN_SUCCESS;
+}
+
+aclnnStatus check_page_tables(const aclTensor* ids, const aclTensor* table, const aclTensor* seq, int Hkv, int* B,
+                              int* kv_page_len, int* max_page) {
+    CHECK(check_tensor(ids, "block_ids", 2, ACL_INT32));
+    CHECK(check_tensor(table, "block_table", 2, ACL_INT32));
+    CHECK(check_tensor(seq, "seq_len", 1, ACL_INT32));
+    REQUIRE(ids->dims[0] == Hkv, "block_ids has %lld rows, expected num kv heads %d", (long long)ids->dims[0], Hkv);
+    *B = (int)seq->dims[0];   // batch comes from seq_len (cent_select_tiling.cpp:32,53)
+    *kv_page_len = (int)ids->dims[1];
+    *max_page = (int)table->dims[1];
+    REQUIRE(*kv_page_len > 0, "block_ids has no pages");
+    REQUIRE(table->dims[0] >= *B, "block_table has %lld rows < batch %d", (long long)table->dims[0], *B);
+    return ACLNN_SUCCESS;
+}
+
+aclnnStatus hip_fail(hipError_t e, const char* what) {
+    return fail(ACLNN_ERR_RUNTIME_ERROR, "%s: %s", what, hipGetErrorString(e));
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// descriptor shim
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+aclTensor* aclCreateTensor(const int64_t* viewDims, uint64_t viewDimsNum, aclDataType dataType, const int64_t* stride,
+                           int64_t offset, aclFormat, const int64_t*, uint64_t, void* tensorData) {
+    if (viewDimsNum > 0 && viewDims == nullptr) return nullptr;
+    aclTensor* t = new aclTensor();
+    t->dims.assign(viewDims, viewDims + viewDimsNum);
+    if (stride) {
+        t->strides.assign(stride, stride + viewDimsNum);
+    } else {
+        t->strides.resize(viewDimsNum);
+        int64_t s = 1;
+        for (int i = (int)viewDimsNum - 1; i >= 0; --i) { t->strides[i] = s; s *= viewDims[i]; }
+    }
+    t->offset = offset;
+    t->dtype = dataType;
+    t->data = tensorData;
+    return t;
+}
+aclnnStatus aclDestroyTensor(const aclTensor* t) { delete t; return ACLNN_SUCCESS; }
+
+aclTensorList* aclCreateTensorList(const aclTensor* const* value, uint64_t size) {
+    aclTensorList* l = new aclTensorList();
+    for (uint64_t i = 0; i < size; ++i) l->items.push_back(const_cast<aclTensor*>(value[i]));
+    return l;
+}
+aclnnStatus aclDestroyTensorList(const aclTensorList* l) {
+    if (l) for (aclTensor* t : l->items) delete t;
+    delete l;
+    return ACLNN_SUCCESS;
+}
+aclIntArray* aclCreateIntArray(const int64_t* value, uint64_t size) {
+    aclIntArray* a = new aclIntArray();
+    if (value) a->v.assign(value, value + size);
+    return a;
+}
+aclnnStatus aclDestroyIntArray(const aclIntArray* a) { delete a; return ACLNN_SUCCESS; }
+
+aclnnStatus aclSetAclOpExecutorRepeatable(aclOpExecutor* e) {
+    if (!e) return fail(ACLNN_ERR_PARAM_NULLPTR, "executor is NULL");
+    e->repeatable = true;
+    return ACLNN_SUCCESS;
+}
+aclnnStatus aclDestroyAclOpExecutor(aclOpExecutor* e) { delete e; return ACLNN_SUCCESS; }
+const char* aclGetRecentErrMsg(void) { return g_err.c_str(); }
+
+int InitHugeMemThreadLocal(void*, bool) { return 0; }
+void UnInitHugeMemThreadLocal(void*, bool) {}
+void ReleaseHugeMem(void*, bool) {}
+
+aclnnStatus spfaSetTopK(int64_t k) {
+    if (k < 1) return fail(ACLNN_ERR_PARAM_INVALID, "top-k must be >= 1, got %lld", (long long)k);
+    g_topk = k;
+    return ACLNN_SUCCESS;
+}
+aclnnStatus spfaSetSinkRecent(int enable) { g_sink_recent = enable ? 1 : 0; return ACLNN_SUCCESS; }
+aclnnStatus spfaSetPageCap(int enable) { g_page_cap = enable ? 1 : 0; return ACLNN_SUCCESS; }
+aclnnStatus spfaSetPageSize(int64_t page_size) {
+    if (page_size < 1 || page_size > 512) return fail(ACLNN_ERR_PARAM_INVALID, "page size %lld out of [1, 512]", (long long)page_size);
+    g_page_size = page_size;
+    return ACLNN_SUCCESS;
+}
+aclnnStatus spfaSetActualSeqLengthsDevice(const int64_t* dev, int64_t n) {
+    g_act_seq_dev = (const long long*)dev;
+    g_act_seq_dev_n = dev ? n : 0;
+    return ACLNN_SUCCESS;
+}
+const char* spfaVersion(void) { return "spfa-hip-gfx950 0.1"; }
+
+// ------------------------------------------------------------------------------------------------
+// ComputeCent
+// ------------------------------------------------------------------------------------------------
+aclnnStatus aclnnComputeCentGetWorkspaceSize(const aclTensor* query, const aclTensor* l1Cent, const aclTensor* indicesOut,
+                                             uint64_t* workspaceSize, aclOpExecutor** executor) {
+    REQUIRE_PTR(workspaceSize, "workspaceSize");
+    REQUIRE_PTR(executor, "executor");
+    int Hq = 0, Hkv = 0, D = 0, C = 0;
+    CHECK(check_qcent(query, l1Cent, &Hq, &Hkv, &D, &C));
+    REQUIRE(query->dims.size() == 3 && query->dims[2] == D, "query must be [B, Hq, %d]", D);
+    CHECK(check_tensor(indicesOut, "indices", 3, ACL_INT32));
+    const int B = (int)query->dims[0];
+    Hq = (int)query->dims[1];
+    REQUIRE(Hq % Hkv == 0, "num heads %d not divisible by num kv heads %d", Hq, Hkv);
+    REQUIRE(indicesOut->dims[0] == B && indicesOut->dims[1] == Hq, "indices must be [B, Hq, k]");
+    const int k = (int)indicesOut->dims[2];   // compute_cent_tiling.cpp:45
+    REQUIRE(k >= 1 && k <= C && k <= 1024, "k = %d must be in [1, min(C = %d, 1024)]", k, C);
+    aclOpExecutor* e = new aclOpExecutor();
+    e->op = kOpComputeCent;
+    spfa::CentParams& p = e->cent;
+    p.q = data_ptr(query);
+    p.cent = data_ptr(l1Cent);
+    p.qk_dtype = to_dtype(query->dtype);
+    p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.G = Hq / Hkv; p.D = D; p.C = C; p.k = k;
+    p.Cp = round_up(C, 64);
+    p.rows_per_pass = score_rows_per_pass(p.G, p.Cp, 8);
+    p.indices = (int32_t*)data_ptr(indicesOut);
+    int npow2 = 64;
+    while (npow2 < k) npow2 <<= 1;
+    p.lds_bytes = (size_t)p.rows_per_pass * p.Cp * 4 + (size_t)4 * npow2 * 8;
+    *workspaceSize = 0;
+    *executor = e;
+    return ACLNN_SUCCESS;
+}
+
+static aclnnStatus finish(aclOpExecutor* e, hipError_t err, const char* what) {
+    if (!e->repeatable) delete e;
+    if (err != hipSuccess) return hip_fail(err, what);
+    return ACLNN_SUCCESS;
+}
+
+aclnnStatus aclnnComputeCent(void*, uint64_t, aclOpExecutor* executor, aclrtStream stream) {
+    REQUIRE_PTR(executor, "executor");
+    REQUIRE(executor->op == kOpComputeCent, "executor was not created by aclnnComputeCentGetWorkspaceSize");
+    return finish(executor, spfa::launch_compute_cent(executor->cent, (hipStream_t)stream), "compute_cent launch");
+}
+
+// ------------------------------------------------------------------------------------------------
+// SelectPosition
+// ------------------------------------------------------------------------------------------------
+aclnnStatus aclnnSelectPositionGetWorkspaceSize(const aclTensor* blockIds, const aclTensor* blockTable,
+                                                const aclTensor* seqLen, const aclTensor* indices,
+                                                const aclTensor* pagePositionOut, const aclTensor* pagePositionLengthOut,
+                                                const aclTensor* blockTableGatherOut, uint64_t* workspaceSize,
+                                                aclOpExecutor** executor) {
+    REQUIRE_PTR(workspaceSize, "workspaceSize");
+    REQUIRE_PTR(executor, "executor");
+    CHECK(check_tensor(indices, "indices", 3, ACL_INT32));
+    REQUIRE_PTR(blockIds, "block_ids");
+    const int Hkv = blockIds->dims.empty() ? 0 : (int)blockIds->dims[0];
+    int B = 0, kv_page_len = 0, max_page = 0;
+    CHECK(check_page_tables(blockIds, blockTable, seqLen, Hkv, &B, &kv_page_len, &max_page));
+    const int Hq = (int)indices->dims[1], k = (int)indices->dims[2];
+    REQUIRE(Hkv > 0 && Hq % Hkv == 0, "num heads %d not divisible by num kv heads %d", Hq, Hkv);
+    REQUIRE(indices->dims[0] >= B, "indices batch %lld < seq_len batch %d", (long long)indices->dims[0], B);
+    REQUIRE(k >= 1 && k <= 4096, "k = %d out of range", k);
+    CHECK(check_tensor(pagePositionOut, "page_position", 3, ACL_INT32));
+    CHECK(check_tensor(pagePositionLengthOut, "page_position_length", 3, ACL_INT32));
+    CHECK(check_tensor(blockTableGatherOut, "block_table_gather", 3, ACL_INT32));
+    REQUIRE(pagePositionOut->dims[0] >= B && pagePositionOut->dims[1] == Hq && pagePositionOut->dims[2] >= 1,
+            "page_position must be [B, Hq, P]");
+    REQUIRE(pagePositionLengthOut->dims[0] >= B && pagePositionLengthOut->dims[1] == Hq &&
+                pagePositionLengthOut->dims[2] == spfa::kLenPad, "page_position_length must be [B, Hq, 8]");
+    REQUIRE(blockTableGatherOut->dims[0] >= B && blockTableGatherOut->dims[1] == Hq &&
+                blockTableGatherOut->dims[2] == max_page, "block_table_gather must be [B, Hq, %d]", max_page);
+    aclOpExecutor* e = new aclOpExecutor();
+    e->op = kOpSelectPosition;
+    spfa::SelectParams& p = e->sel;
+    p.block_ids = (const int32_t*)data_ptr(blockIds);
+    p.block_table = (const int32_t*)data_ptr(blockTable);
+    p.seq_len = (const int32_t*)data_ptr(seqLen);
+    p.indices = (const int32_t*)data_ptr(indices);
+    p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.G = Hq / Hkv; p.k = k;
+    p.kv_page_len = kv_page_len; p.max_page = max_page; p.block_size = (int)g_page_size;
+    p.P = (int)pagePositionOut->dims[2];
+    p.page_position = (int32_t*)data_ptr(pagePositionOut);
+    p.page_position_length = (int32_t*)data_ptr(pagePositionLengthOut);
+    p.block_table_gather = (int32_t*)data_ptr(blockTableGatherOut);
+    *workspaceSize = 0;
+    *executor = e;
+    return ACLNN_SUCCESS;
+}
+
+aclnnStatus aclnnSelectPosition(void*, uint64_t, aclOpExecutor* executor, aclrtStream stream) {
+    REQUIRE_PTR(executor, "executor");
+    REQUIRE(executor->op == kOpSelectPosition, "executor was not created by aclnnSelectPositionGetWorkspaceSize");
+    return finish(executor, spfa::launch_select_position(executor->sel, (hipStream_t)stream), "select_position launch");
+}
+
+// ------------------------------------------------------------------------------------------------
+// CentSelect
+// ------------------------------------------------------------------------------------------------
+aclnnStatus aclnnCentSelectGetWorkspaceSize(const aclTensor* query, const aclTensor* l1Cent, const aclTensor* blockIds,
+                                            const aclTensor* blockTable, const aclTensor* seqLen, const aclTensor*,
+                                            const aclTensor* pagePositionOut, const aclTensor* pagePositionLengthOut,
+                                            const aclTensor* maxPagePositionLengthOut, uint64_t* workspaceSize,
+                                            aclOpExecutor** executor) {
+    REQUIRE_PTR(workspaceSize, "workspaceSize");
+    REQUIRE_PTR(executor, "executor");
+    int Hq = 0, Hkv = 0, D = 0, C = 0;
+    CHECK(check_qcent(query, l1Cent, &Hq, &Hkv, &D, &C));
+    REQUIRE(query->dims.size() == 3 && query->dims[2] == D, "query must be [B, Hq, %d]", D);
+    Hq = (int)query->dims[1];
+    REQUIRE(Hq % Hkv == 0, "num heads %d not divisible by num kv heads %d", Hq, Hkv);
+    int B = 0, kv_page_len = 0, max_page = 0;
+    CHECK(check_page_tables(blockIds, blockTable, seqLen, Hkv, &B, &kv_page_len, &max_page));
+    REQUIRE(query->dims[0] >= B, "query batch %lld < seq_len batch %d", (long long)query->dims[0], B);
+    const int k = (int)g_topk;
+    REQUIRE(k <= C, "top-k %d exceeds the cluster count %d", k, C);
+    CHECK(check_tensor(pagePositionOut, "page_position", 3, ACL_INT32));
+    CHECK(check_tensor(pagePositionLengthOut, "page_position_length", 3, ACL_INT32));
+    CHECK(check_tensor(maxPagePositionLengthOut, "max_page_position_length", 2, ACL_INT64));
+    REQUIRE(pagePositionOut->dims[0] >= B && pagePositionOut->dims[1] == Hq && pagePositionOut->dims[2] >= 1,
+            "page_position must be [B, Hq, P]");
+    REQUIRE(pagePositionLengthOut->dims[0] >= B && pagePositionLengthOut->dims[1] == Hq &&
+                pagePositionLengthOut->dims[2] == spfa::kLenPad, "page_position_length must be [B, Hq, 8]");
+    REQUIRE(maxPagePositionLengthOut->dims[0] >= B && maxPagePositionLengthOut->dims[1] == spfa::kLenPad,
+            "max_page_position_length must be [B, 8]");
+    aclOpExecutor* e = new aclOpExecutor();
+    e->op = kOpCentSelect;
+    spfa::CentParams& p = e->cent;
+    p.q = data_ptr(query);
+    p.cent = data_ptr(l1Cent);
+    p.qk_dtype = to_dtype(query->dtype);
+    p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.G = Hq / Hkv; p.D = D; p.C = C; p.k = k;
+    p.Cp = round_up(C, 64);
+    p.rows_per_pass = score_rows_per_pass(p.G, p.Cp, 8);
+    p.block_ids = (const int32_t*)data_ptr(blockIds);
+    p.block_table = (const int32_t*)data_ptr(blockTable);
+    p.seq_len = (const int32_t*)data_ptr(seqLen);
+    p.kv_page_len = kv_page_len; p.max_page = max_page; p.block_size = (int)g_page_size;
+    p.P = (int)pagePositionOut->dims[2];
+    p.sink_recent = g_sink_recent; p.cap_pages = g_page_cap;
+    p.page_position = (int32_t*)data_ptr(pagePositionOut);
+    p.page_position_length = (int32_t*)data_ptr(pagePositionLengthOut);
+    p.max_page_position_length = (unsigned long long*)data_ptr(maxPagePositionLengthOut);
+    p.lds_bytes = (size_t)p.rows_per_pass * p.Cp * 4 + (size_t)4 * (p.Cp / 32) * 4;
+    *workspaceSize = 0;
+    *executor = e;
+    return ACLNN_SUCCESS;
+}
+
+aclnnStatus aclnnCentSelect(void*, uint64_t, aclOpExecutor* executor, aclrtStream stream) {
+    REQUIRE_PTR(executor, "executor");
+    REQUIRE(executor->op == kOpCentSelect, "executor was not created by aclnnCentSelectGetWorkspaceSize");
+    const spfa::CentParams& p = executor->cent;
+    hipError_t err = hipSuccess;
+    if (p.B > 0)   // the per-batch maximum is accumulated with atomicMax
+        err = hipMemsetAsync(p.max_page_position_length, 0, (size_t)p.B * spfa::kLenPad * 8, (hipStream_t)stream);
+    if (err == hipSuccess) err = spfa::launch_cent_select(p, (hipStream_t)stream);
+    return finish(executor, err, "cent_select launch");
+}
+
+// ------------------------------------------------------------------------------------------------
+// SparsePagedAttention / SparsePagedFusionAttention
+// ------------------------------------------------------------------------------------------------
+static aclnnStatus plan_attention(spfa::AttnParams& p, const aclTensor* query, const aclTensorList* key,
+                                  const aclTensorList* value, const aclTensor* antiquantScale,
+                                  const aclTensor* antiquantOffset, const aclTensor* blocktable, int64_t numHeads,
+                                  double scaleValue, const char* inputLayout, int64_t numKeyValueHeads,
+                                  int64_t blockSize, const aclTensor* attentionOut, int batch_limit) {
+    REQUIRE_PTR(query, "query");
+    REQUIRE(query->dtype == ACL_FLOAT16 || query->dtype == ACL_BF16, "query must be float16 or bfloat16");
+    REQUIRE(is_contiguous(query), "query must be contiguous");
+    REQUIRE(numHeads > 0, "numHeads must be positive");
+    const int Hq = (int)numHeads;
+    const int Hkv = numKeyValueHeads > 0 ? (int)numKeyValueHeads : Hq;
+    REQUIRE(Hq % Hkv == 0, "numHeads %d not divisible by numKeyValueHeads %d", Hq, Hkv);
+    REQUIRE(Hq / Hkv <= 64, "group size %d exceeds 64 (…_tiling_check.cc:171)", Hq / Hkv);
+    const std::string layout = inputLayout ? inputLayout : "BNSD";
+    // decode only: S = 1, so every accepted layout is [B, Hq, D] in memory
+    int B = 0, D = 0;
+    const auto& qd = query->dims;
+    if (qd.size() == 3 && layout == "BSH") {            // [B, 1, Hq*D]
+        REQUIRE(qd[1] == 1 && qd[2] % Hq == 0, "BSH query must be [B, 1, numHeads*D]");
+        B = (int)qd[0]; D = (int)(qd[2] / Hq);
+    } else if (qd.size() == 3) {                        // [B, Hq, D] (…attention_tiling.cc:207-225)
+        REQUIRE(qd[1] == Hq, "query must be [B, numHeads = %d, D]", Hq);
+        B = (int)qd[0]; D = (int)qd[2];
+    } else if (qd.size() == 4 && layout == "BSND") {    // [B, 1, Hq, D]
+        REQUIRE(qd[1] == 1 && qd[2] == Hq, "BSND query must be [B, 1, numHeads, D]");
+        B = (int)qd[0]; D = (int)qd[3];
+    } else if (qd.size() == 4) {                        // BNSD [B, Hq, 1, D]
+        REQUIRE(qd[1] == Hq && qd[2] == 1, "BNSD query must be [B, numHeads, 1, D] (decode: one query token)");
+        B = (int)qd[0]; D = (int)qd[3];
+    } else {
+        return fail(ACLNN_ERR_PARAM_INVALID, "query must have 3 or 4 dims");
+    }
+    REQUIRE(D > 0 && D <= 512, "head dim %d out of range (…_tiling_check.cc:219)", D);
+    REQUIRE(Hkv <= 256, "numKeyValueHeads %d exceeds 256 (…_tiling_check.cc:222)", Hkv);
+
+    REQUIRE(key && key->items.size() == 1 && value && value->items.size() == 1,
+            "key / value must be one-tensor lists holding the paged cache");
+    const aclTensor* kc = key->items[0];
+    const aclTensor* vc = value->items[0];
+    REQUIRE(kc->dtype == vc->dtype && kc->dims == vc->dims, "key and value cache must agree in dtype and shape");
+    REQUIRE(is_contiguous(kc) && is_contiguous(vc), "key / value cache must be contiguous");
+    REQUIRE(kc->data && vc->data, "key / value cache has no device memory");
+    const bool quant = kc->dtype == ACL_INT8;
+    REQUIRE(quant || kc->dtype == query->dtype,
+            "KV cache dtype must equal the query dtype or be int8 (…_tiling_check.cc:178-182)");
+    const int es = quant ? 1 : 2;
+    REQUIRE(blockSize > 0 && blockSize <= 512, "blockSize %lld out of (0, 512] (…_tiling_check.cc:28-48)", (long long)blockSize);
+    REQUIRE(blockSize % (quant ? 32 : 16) == 0, "blockSize %lld must be a multiple of %d (…_tiling_check.cc:188-191)",
+            (long long)blockSize, quant ? 32 : 16);
+    const int bs = (int)blockSize;
+    const auto& kd = kc->dims;
+    bool bsh;
+    if (kd.size() == 3) {
+        REQUIRE(kd[1] == bs && kd[2] == (int64_t)Hkv * D, "KV cache must be [blocks, blockSize, Hkv*D]");
+        bsh = true;
+    } else if (kd.size() == 4 && kd[1] == bs && kd[2] == Hkv && kd[3] == D) {
+        bsh = true;    // [blocks, bs, Hkv, D]: the vLLM layout the fused op forces (…_tiling.cc:338)
+    } else if (kd.size() == 4 && kd[1] == Hkv && kd[2] == bs && kd[3] == D) {
+        bsh = false;   // [blocks, Hkv, bs, D]
+    } else {
+        return fail(ACLNN_ERR_PARAM_INVALID, "KV cache must be [blocks,bs,Hkv*D], [blocks,bs,Hkv,D] or [blocks,Hkv,bs,D]");
+    }
+    const int lpt = D * es / 16;
+    REQUIRE((D * es) % 16 == 0 && (lpt == 4 || lpt == 8 || lpt == 16 || lpt == 32),
+            "head dim %d with %d-byte KV elements is not supported (row bytes must be 64, 128, 256 or 512)", D, es);
+    REQUIRE(kd[0] > 0 && kd[0] <= 0x7fffffff, "KV cache has no blocks");
+
+    if (quant) {
+        REQUIRE(!absent(antiquantScale), "int8 KV cache needs antiquantScale");
+        REQUIRE(antiquantScale->dtype == query->dtype && numel(antiquantScale) == 2ll * Hkv * D &&
+                    is_contiguous(antiquantScale),
+                "antiquantScale must be [2, Hkv, D] in the query dtype (…_tiling_check.cc:497-525)");
+        if (!absent(antiquantOffset))
+            REQUIRE(antiquantOffset->dtype == query->dtype && numel(antiquantOffset) == 2ll * Hkv * D &&
+                        is_contiguous(antiquantOffset),
+                    "antiquantOffset must be [2, Hkv, D] in the query dtype");
+    } else {
+        REQUIRE(absent(antiquantScale) && absent(antiquantOffset),
+                "antiquant parameters given but the KV cache is not int8 (…_tiling.cc:862-866)");
+    }
+    CHECK(check_tensor(blocktable, "blocktable", 2, ACL_INT32));
+    REQUIRE_PTR(attentionOut, "attentionOut");
+    REQUIRE(attentionOut->dtype == query->dtype || attentionOut->dtype == ACL_FLOAT,
+            "attentionOut dtype must equal the query dtype (or float32)");
+    REQUIRE(numel(attentionOut) == numel(query) && is_contiguous(attentionOut), "attentionOut must have query's shape");
+    if (batch_limit >= 0) {
+        REQUIRE(B >= batch_limit, "query batch %d < total_seq_len batch %d", B, batch_limit);
+        B = batch_limit;
+    }
+    REQUIRE(blocktable->dims[0] >= B, "blocktable has %lld rows < batch %d", (long long)blocktable->dims[0], B);
+
+    p.q = data_ptr(query);
+    p.out = data_ptr(attentionOut);
+    p.q_dtype = to_dtype(query->dtype);
+    p.out_dtype = to_dtype(attentionOut->dtype);
+    p.kv_dtype = to_dtype(kc->dtype);
+    p.kcache = data_ptr(kc);
+    p.vcache = data_ptr(vc);
+    if (bsh) {
+        p.blk_stride = (long long)bs * Hkv * D * es; p.tok_stride = (long long)Hkv * D * es; p.head_stride = (long long)D * es;
+    } else {
+        p.blk_stride = (long long)Hkv * bs * D * es; p.head_stride = (long long)bs * D * es; p.tok_stride = (long long)D * es;
+    }
+    p.n_blocks = (int)kd[0];
+    p.block_table = (const int32_t*)data_ptr(blocktable);
+    p.max_page = (int)blocktable->dims[1];
+    p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.G = Hq / Hkv; p.D = D; p.block_size = bs;
+    p.scale = (float)scaleValue;
+    p.antiq_scale = quant ? data_ptr(antiquantScale) : nullptr;
+    p.antiq_offset = (quant && !absent(antiquantOffset)) ? data_ptr(antiquantOffset) : nullptr;
+    return ACLNN_SUCCESS;
+}
+
+static aclnnStatus plan_lds(spfa::AttnParams& p) {
+    const bool per_head = (p.mode == 0 && p.pos_rows == p.Hq && p.G > 1);
+    p.rows_per_pass = per_head ? 1 : spfa::attention_rows_per_pass(p.G, p.kv_dtype);
+    const int nq = p.rows_per_pass;
+    size_t region = (size_t)4 * nq * (p.D + 2) * 4;                       // cross-wave merge
+    region = std::max(region, (size_t)16 * (size_t)p.max_entries);        // page list
+    size_t cbits = 0, pbits = 0;
+    if (p.mode == 1) {
+        REQUIRE((size_t)nq * p.Cp * 4 <= 96 * 1024, "cluster count %d too large for the fused kernel", p.C);
+        region = std::max(region, (size_t)nq * p.Cp * 4);                 // score keys
+        cbits = (size_t)4 * (p.Cp / 32) * 4;
+        pbits = (size_t)nq * ((p.max_page + 63) / 64) * 8;
+    }
+    region = (region + 15) & ~(size_t)15;
+    p.off_cbits = (int)region;
+    p.off_pbits = (int)(region + cbits);
+    p.off_misc = (int)(region + cbits + pbits);
+    p.lds_bytes = region + cbits + pbits + 16;
+    REQUIRE(p.lds_bytes <= kMaxLds, "page list of %d entries / %d clusters needs %zu bytes of LDS (> %zu)", p.max_entries,
+            p.C, p.lds_bytes, kMaxLds);
+    return ACLNN_SUCCESS;
+}
+
+#define REJECT_PRESENT(t, name) \
+    REQUIRE(absent(t), "%s is not supported on the sparse paged path (must be empty)", name)
+
+aclnnStatus aclnnSparsePagedAttentionGetWorkspaceSize(
+    const aclTensor* query, const aclTensorList* key, const aclTensorList* value, const aclTensor* pseShift,
+    const aclTensor* attenMask, const aclIntArray* actualSeqLengths, const aclTensor* dequantScale1,
+    const aclTensor* quantScale1, const aclTensor* dequantScale2, const aclTensor* quantScale2,
+    const aclTensor* quantOffset2, const aclTensor* antiquantScale, const aclTensor* antiquantOffset,
+    const aclTensor* blocktable, const aclTensor* kvPaddingSize, const aclTensor* blockposition, int64_t numHeads,
+    double scaleValue, char* inputLayout, int64_t numKeyValueHeads, int64_t blockSize, int64_t /*innerPrecise*/,
+    const aclTensor* attentionOut, uint64_t* workspaceSize, aclOpExecutor** executor) {
+    REQUIRE_PTR(workspaceSize, "workspaceSize");
+    REQUIRE_PTR(executor, "executor");
+    REJECT_PRESENT(pseShift, "pseShift");
+    REJECT_PRESENT(attenMask, "attenMask");
+    REJECT_PRESENT(dequantScale1, "dequantScale1");
+    REJECT_PRESENT(quantScale1, "quantScale1");
+    REJECT_PRESENT(dequantScale2, "dequantScale2");
+    REJECT_PRESENT(quantScale2, "quantScale2");
+    REJECT_PRESENT(quantOffset2, "quantOffset2");
+    REJECT_PRESENT(kvPaddingSize, "kvPaddingSize");
+    aclOpExecutor* e = new aclOpExecutor();
+    e->op = kOpAttention;
+    spfa::AttnParams& p = e->attn;
+    p.mode = 0;
+    aclnnStatus st = plan_attention(p, query, key, value, antiquantScale, antiquantOffset, blocktable, numHeads,
+                                    scaleValue, inputLayout, numKeyValueHeads, blockSize, attentionOut, -1);
+    auto bail = [&](aclnnStatus s) { delete e; return s; };
+    if (st != ACLNN_SUCCESS) return bail(st);
+    st = check_tensor(blockposition, "blockposition", 3, ACL_INT32);
+    if (st != ACLNN_SUCCESS) return bail(st);
+    const int rows = (int)blockposition->dims[1];
+    if (blockposition->dims[0] < p.B || (rows != p.Hq && rows != p.Hkv) || blockposition->dims[2] < 1)
+        return bail(fail(ACLNN_ERR_PARAM_INVALID, "blockposition must be [B, numHeads | numKeyValueHeads, P]"));
+    p.block_position = (const int32_t*)data_ptr(blockposition);
+    p.pos_rows = rows;
+    p.P = (int)blockposition->dims[2];
+    p.max_entries = p.P;
+    p.act_seq_uniform = -1;
+    if (g_act_seq_dev) {   // extension: lengths already on the device, no host round trip
+        if (g_act_seq_dev_n < p.B)
+            return bail(fail(ACLNN_ERR_PARAM_INVALID, "device actualSeqLengths has %lld values < batch %d",
+                             (long long)g_act_seq_dev_n, p.B));
+        p.act_seq = g_act_seq_dev;
+        g_act_seq_dev = nullptr;
+    } else if (actualSeqLengths && !actualSeqLengths->v.empty()) {
+        const auto& v = actualSeqLengths->v;
+        if (v.size() != 1 && (int)v.size() < p.B)
+            return bail(fail(ACLNN_ERR_PARAM_INVALID, "actualSeqLengths has %zu values, expected 1 or batch %d", v.size(), p.B));
+        bool uniform = true;
+        for (int b = 1; b < p.B && v.size() > 1; ++b) uniform = uniform && v[b] == v[0];
+        if (uniform) {
+            p.act_seq_uniform = v[0];
+        } else {
+            e->act_seq.assign(v.begin(), v.begin() + p.B);
+            e->ws_bytes = ((uint64_t)p.B * 8 + 255) & ~255ull;
+        }
+    }
+    st = plan_lds(p);
+    if (st != ACLNN_SUCCESS) return bail(st);
+    *workspaceSize = e->ws_bytes;
+    *executor = e;
+    return ACLNN_SUCCESS;
+}
+
+aclnnStatus aclnnSparsePagedAttention(void* workspace, uint64_t workspaceSize, aclOpExecutor* executor,
+                                      const aclrtStream stream) {
+    REQUIRE_PTR(executor, "executor");
+    REQUIRE(executor->op == kOpAttention, "executor was not created by aclnnSparsePagedAttentionGetWorkspaceSize");
+    spfa::AttnParams p = executor->attn;
+    hipError_t err = hipSuccess;
+    if (!executor->act_seq.empty()) {
+        if (workspace == nullptr || workspaceSize < executor->ws_bytes) {
+            if (!executor->repeatable) delete executor;
+            return fail(ACLNN_ERR_PARAM_INVALID, "workspace of %llu bytes required", (unsigned long long)executor->ws_bytes);
+        }
+        // Per-batch lengths travel through the workspace.  A one-shot executor dies when this call
+        // returns, so its host copy is handed to the stream and freed there after the copy ran.
+        const long long* src = executor->act_seq.data();
+        std::vector<long long>* parked = nullptr;
+        if (!executor->repeatable) {
+            parked = new std::vector<long long>(std::move(executor->act_seq));
+            src = parked->data();
+        }
+        err = hipMemcpyAsync(workspace, src, (size_t)p.B * 8, hipMemcpyHostToDevice, (hipStream_t)stream);
+        if (parked) {
+            hipError_t e2 = hipLaunchHostFunc((hipStream_t)stream, [](void* v) { delete (std::vector<long long>*)v; }, parked);
+            if (e2 != hipSuccess) {   // could not enqueue the release: wait, then free here
+                (void)hipStreamSynchronize((hipStream_t)stream);
+                delete parked;
+            }
+        }
+        p.act_seq = (const long long*)workspace;
+    }
+    if (err == hipSuccess) err = spfa::launch_attention(p, (hipStream_t)stream);
+    return finish(executor, err, "sparse_paged_attention launch");
+}
+
+aclnnStatus aclnnSparsePagedFusionAttentionGetWorkspaceSize(
+    const aclTensor* query, const aclTensorList* key, const aclTensorList* value, const aclTensor* pseShift,
+    const aclTensor* attenMask, const aclIntArray* /*actualSeqLengths: tiling hint only*/, const aclTensor* dequantScale1,
+    const aclTensor* quantScale1, const aclTensor* dequantScale2, const aclTensor* quantScale2,
+    const aclTensor* quantOffset2, const aclTensor* antiquantScale, const aclTensor* antiquantOffset,
+    const aclTensor* blocktable, const aclTensor* kvPaddingSize, const aclTensor* l1_cent, const aclTensor* block_ids,
+    const aclTensor* total_seq_len, int64_t numHeads, double scaleValue, char* inputLayout, int64_t numKeyValueHeads,
+    int64_t blockSize, int64_t /*innerPrecise*/, const aclTensor* block_position, const aclTensor* page_position_length,
+    const aclTensor* max_page_position_length, const aclTensor* attentionOut, uint64_t* workspaceSize,
+    aclOpExecutor** executor) {
+    REQUIRE_PTR(workspaceSize, "workspaceSize");
+    REQUIRE_PTR(executor, "executor");
+    REJECT_PRESENT(pseShift, "pseShift");
+    REJECT_PRESENT(attenMask, "attenMask");
+    REJECT_PRESENT(dequantScale1, "dequantScale1");
+    REJECT_PRESENT(quantScale1, "quantScale1");
+    REJECT_PRESENT(dequantScale2, "dequantScale2");
+    REJECT_PRESENT(quantScale2, "quantScale2");
+    REJECT_PRESENT(quantOffset2, "quantOffset2");
+    REJECT_PRESENT(kvPaddingSize, "kvPaddingSize");
+    int Hq = 0, Hkv = 0, D = 0, C = 0;
+    CHECK(check_qcent(query, l1_cent, &Hq, &Hkv, &D, &C));
+    int B = 0, kv_page_len = 0, max_page = 0;
+    CHECK(check_page_tables(block_ids, blocktable, total_seq_len, Hkv, &B, &kv_page_len, &max_page));
+    aclOpExecutor* e = new aclOpExecutor();
+    e->op = kOpFusion;
+    spfa::AttnParams& p = e->attn;
+    p.mode = 1;
+    auto bail = [&](aclnnStatus s) { delete e; return s; };
+    aclnnStatus st = plan_attention(p, query, key, value, antiquantScale, antiquantOffset, blocktable, numHeads,
+                                    scaleValue, inputLayout, numKeyValueHeads, blockSize, attentionOut, B);
+    if (st != ACLNN_SUCCESS) return bail(st);
+    if (p.Hkv != Hkv || p.D != D)
+        return bail(fail(ACLNN_ERR_PARAM_INVALID, "l1_cent [%d, %d, %d] does not match numKeyValueHeads %d / head dim %d",
+                         Hkv, C, D, p.Hkv, p.D));
+    const int k = (int)g_topk;
+    if (k > C) return bail(fail(ACLNN_ERR_PARAM_INVALID, "top-k %d exceeds the cluster count %d", k, C));
+    p.cent = data_ptr(l1_cent);
+    p.block_ids = (const int32_t*)data_ptr(block_ids);
+    p.seq_len = (const int32_t*)data_ptr(total_seq_len);
+    p.C = C; p.Cp = round_up(C, 64); p.k = k; p.kv_page_len = kv_page_len;
+    p.sink_recent = g_sink_recent; p.cap_pages = g_page_cap;
+    p.P = max_page;
+    if (!absent(block_position)) {
+        st = check_tensor(block_position, "block_position", 3, ACL_INT32);
+        if (st != ACLNN_SUCCESS) return bail(st);
+        if (block_position->dims[0] < B || block_position->dims[1] != p.Hq || block_position->dims[2] < 1)
+            return bail(fail(ACLNN_ERR_PARAM_INVALID, "block_position must be [B, numHeads, P]"));
+        p.page_position = (int32_t*)data_ptr(block_position);
+        p.P = (int)block_position->dims[2];
+    }
+    if (!absent(page_position_length)) {
+        st = check_tensor(page_position_length, "page_position_length", 3, ACL_INT32);
+        if (st != ACLNN_SUCCESS) return bail(st);
+        if (page_position_length->dims[0] < B || page_position_length->dims[1] != p.Hq ||
+            page_position_length->dims[2] != spfa::kLenPad)
+            return bail(fail(ACLNN_ERR_PARAM_INVALID, "page_position_length must be [B, numHeads, 8]"));
+        p.page_position_length = (int32_t*)data_ptr(page_position_length);
+    }
+    if (!absent(max_page_position_length)) {
+        st = check_tensor(max_page_position_length, "max_page_position_length", 2, ACL_INT64);
+        if (st != ACLNN_SUCCESS) return bail(st);
+        if (max_page_position_length->dims[0] < B || max_page_position_length->dims[1] != spfa::kLenPad)
+            return bail(fail(ACLNN_ERR_PARAM_INVALID, "max_page_position_length must be [B, 8]"));
+        p.max_page_position_length = (unsigned long long*)data_ptr(max_page_position_length);
+    }
+    p.max_entries = max_page;   // the union of a group's lists never exceeds the logical page count
+    st = plan_lds(p);
+    if (st != ACLNN_SUCCESS) return bail(st);
+    *workspaceSize = 0;
+    *executor = e;
+    return ACLNN_SUCCESS;
+}
+
+aclnnStatus aclnnSparsePagedFusionAttention(void*, uint64_t, aclOpExecutor* executor, const aclrtStream stream) {
+    REQUIRE_PTR(executor, "executor");
+    REQUIRE(executor->op == kOpFusion, "executor was not created by aclnnSparsePagedFusionAttentionGetWorkspaceSize");
+    const spfa::AttnParams& p = executor->attn;
+    hipError_t err = hipSuccess;
+    if (p.max_page_position_length && p.B > 0)
+        err = hipMemsetAsync(p.max_page_position_length, 0, (size_t)p.B * spfa::kLenPad * 8, (hipStream_t)stream);
+    if (err == hipSuccess) err = spfa::launch_attention(p, (hipStream_t)stream);
+    return finish(executor, err, "sparse_paged_fusion_attention launch");
+}
+
+}  // extern "C"

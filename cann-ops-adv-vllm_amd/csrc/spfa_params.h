@@ -1,0 +1,96 @@
+// Plain-old-data launch descriptors shared by the host planner (aclnn_ops.cpp) and the
+// gfx950 kernels (spfa_kernels.hip).  They play the role of the reference's tiling structs
+// (CentSelectTilingData, cent_select_tiling.h:5-27; SparsePagedFusionAttentionTilingData,
+// sparse_paged_fusion_attention_tiling.h:131-142): the only channel host -> kernel.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+namespace spfa {
+
+constexpr int kSentinel = 0x7fffffff;   // cent_select.cpp:406
+constexpr int kLenPad = 8;              // page_position_length / max_page_position_length lanes
+constexpr int kThreads = 256;           // 4 wave64 per workgroup
+
+enum DType : int { kF16 = 0, kBF16 = 1, kI8 = 2, kF32 = 3 };
+
+// ComputeCent / CentSelect (no attention).  One workgroup per (batch, kv head).
+struct CentParams {
+    const void* q;             // [Bq, Hq, D]   f16 | bf16
+    const void* cent;          // [Hkv, C, D]   same dtype
+    int qk_dtype;              // kF16 | kBF16
+    int B, Hq, Hkv, G, D, C, k;
+    int rows_per_pass;         // q heads of a group scored per pass (LDS budget)
+    int Cp;                    // C rounded up to 64
+    // mode 0: compute_cent (sorted indices out)
+    int32_t* indices;          // [B, Hq, k]
+    // mode 1: cent_select
+    const int32_t* block_ids;  // [Hkv, kv_page_len]
+    const int32_t* block_table;// [max_batch, max_page]
+    const int32_t* seq_len;    // [B]
+    int kv_page_len, max_page, block_size;
+    int P;                     // slots per page_position row
+    int sink_recent, cap_pages;
+    int32_t* page_position;        // [B, Hq, P]
+    int32_t* page_position_length; // [B, Hq, 8]
+    unsigned long long* max_page_position_length; // [B, 8] (int64, non negative)
+    size_t lds_bytes;
+};
+
+// SelectPosition.  One wave per (batch, q head).
+struct SelectParams {
+    const int32_t* block_ids;   // [Hkv, kv_page_len]
+    const int32_t* block_table; // [max_batch, max_page]
+    const int32_t* seq_len;     // [B]
+    const int32_t* indices;     // [B, Hq, k]
+    int B, Hq, Hkv, G, k, kv_page_len, max_page, block_size, P;
+    int32_t* page_position;        // [B, Hq, P]
+    int32_t* page_position_length; // [B, Hq, 8]
+    int32_t* block_table_gather;   // [B, Hq, max_page]
+};
+
+// SparsePagedAttention (mode 0) and SparsePagedFusionAttention (mode 1).
+struct AttnParams {
+    int mode;                  // 0: page lists given (block_position), 1: fused cent-select first
+    const void* q;             // [B, Hq, D]
+    void* out;                 // [B, Hq, D]
+    int q_dtype, out_dtype, kv_dtype;
+    const void* kcache;        // BSH [blocks, bs, Hkv, D] | BNSD [blocks, Hkv, bs, D]
+    const void* vcache;
+    long long blk_stride, tok_stride, head_stride;   // bytes
+    int n_blocks;
+    const int32_t* block_table;// [>=B, max_page]
+    int max_page;
+    int B, Hq, Hkv, G, D, block_size;
+    float scale;
+    const void* antiq_scale;   // [2, Hkv*D] in q dtype, or null
+    const void* antiq_offset;  // [2, Hkv*D] in q dtype, or null
+    // mode 0
+    const int32_t* block_position; // [B, rows, P]
+    int pos_rows;                  // Hq or Hkv
+    const long long* act_seq;      // device [B] or null
+    long long act_seq_uniform;     // >= 0: one length for every batch; < 0 and act_seq null: whole list
+    // mode 1
+    const void* cent;              // [Hkv, C, D] in q dtype
+    const int32_t* block_ids;      // [Hkv, kv_page_len]
+    const int32_t* seq_len;        // [B] total_seq_len
+    int C, Cp, k, kv_page_len, sink_recent, cap_pages;
+    int32_t* page_position;        // [B, Hq, P] out (may be null)
+    int32_t* page_position_length; // [B, Hq, 8] out (may be null)
+    unsigned long long* max_page_position_length; // [B, 8] out (may be null)
+    int P;                         // slots per row (both modes)
+    int rows_per_pass;             // q heads of a group handled per pass
+    int max_entries;               // capacity of the per-workgroup page list
+    // LDS carve (bytes from the dynamic base)
+    int off_cbits, off_pbits, off_misc;
+    size_t lds_bytes;
+};
+
+hipError_t launch_compute_cent(const CentParams& p, hipStream_t s);
+hipError_t launch_cent_select(const CentParams& p, hipStream_t s);
+hipError_t launch_select_position(const SelectParams& p, hipStream_t s);
+hipError_t launch_attention(const AttnParams& p, hipStream_t s);
+// Number of q heads of a group an attention pass can hold in registers for this G.
+int attention_rows_per_pass(int G, int kv_dtype);
+
+}  // namespace spfa

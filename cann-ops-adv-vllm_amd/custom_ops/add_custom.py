@@ -1,0 +1,190 @@
+"""`custom_ops.*` operator surface on MI355X.
+
+Same function names, positional argument order and return tuples as the reference's
+extension/custom_ops/add_custom.py (:41-135); every call goes through the aclnn-style C-ABI of
+libcust_opapi.so on torch's current HIP stream.  Optional operands follow the reference's
+convention: an empty tensor (numel() == 0) means "absent" (extension/csrc/add_custom.cpp:32-35).
+
+Keyword-only extras (not in the reference, which hard-codes them):
+  k             top-k clusters (reference: 64, add_custom.cpp:940 / cent_select_tiling.cpp:58)
+  sink_recent   also select logical pages 0, pageLen-2, pageLen-1 (cent_select.cpp:350-362)
+  max_pages_cap clip page_position_length to pageLen // 8 (cent_select.cpp:218,410-414)
+  max_page_num  slots per page_position row (reference: 256, add_custom.cpp:958,987)
+  page_size     page size of cent_select / select_position (reference: 128, cent_select.cpp:17)
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple, Union
+
+import torch
+
+from . import _abi
+
+_SENTINEL = 0x7FFFFFFF
+
+
+def _destroy(tensors=(), lists=(), arrays=()):
+    for d in tensors:
+        if d is not None:
+            _abi.aclDestroyTensor(d)
+    for d in lists:
+        if d is not None:
+            _abi.aclDestroyTensorList(d)
+    for d in arrays:
+        if d is not None:
+            _abi.aclDestroyIntArray(d)
+
+
+def _set_knobs(k=None, sink_recent=False, max_pages_cap=False, page_size=128):
+    if k is not None:
+        _abi.check(_abi.spfaSetTopK(int(k)), "spfaSetTopK")
+    _abi.check(_abi.spfaSetSinkRecent(int(bool(sink_recent))), "spfaSetSinkRecent")
+    _abi.check(_abi.spfaSetPageCap(int(bool(max_pages_cap))), "spfaSetPageCap")
+    _abi.check(_abi.spfaSetPageSize(int(page_size)), "spfaSetPageSize")
+
+
+def incre_flash_attention_v4(*args, **kwargs):
+    """Stock dense IncreFlashAttention (add_custom.py:10-40): not part of the sparse paged path."""
+    raise NotImplementedError("incre_flash_attention_v4 is outside the sparse paged attention path")
+
+
+def compute_cent(query: torch.Tensor, l1_cent: torch.Tensor, *, k: int = 64) -> torch.Tensor:
+    """indices[b,h,:k] of the k best centroids of kv head h//G for q[b,h] (add_custom.py:77-81;
+    binding add_custom.cpp:937-953 allocates [B,Hq,64] int32)."""
+    _abi.require_gpu(query, l1_cent)
+    out = torch.empty((query.shape[0], query.shape[1], int(k)), dtype=torch.int32, device=query.device)
+    descs = [_abi.to_acl(query), _abi.to_acl(l1_cent), _abi.to_acl(out)]
+    try:
+        _abi.run(_abi.aclnnComputeCentGetWorkspaceSize, _abi.aclnnComputeCent, descs, query.device, "aclnnComputeCent")
+    finally:
+        _destroy(descs)
+    return out
+
+
+def select_position(block_ids: torch.Tensor, block_table: torch.Tensor, seq_len: torch.Tensor,
+                    indices: torch.Tensor, *, max_page_num: int = 256, page_size: int = 128
+                    ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """(page_position [B,Hq,256], page_position_length [B,Hq,8], block_table_gather [B,Hq,maxPage])
+    (add_custom.py:83-87; binding add_custom.cpp:955-977)."""
+    _abi.require_gpu(block_ids, block_table, seq_len, indices)
+    B, Hq = indices.shape[0], indices.shape[1]
+    dev = block_ids.device
+    pos = torch.empty((B, Hq, int(max_page_num)), dtype=torch.int32, device=dev)
+    length = torch.empty((B, Hq, 8), dtype=torch.int32, device=dev)
+    gather = torch.empty((B, Hq, block_table.shape[1]), dtype=torch.int32, device=dev)
+    _set_knobs(page_size=page_size)
+    descs = [_abi.to_acl(t) for t in (block_ids, block_table, seq_len, indices, pos, length, gather)]
+    try:
+        _abi.run(_abi.aclnnSelectPositionGetWorkspaceSize, _abi.aclnnSelectPosition, descs, dev, "aclnnSelectPosition")
+    finally:
+        _destroy(descs)
+    return pos, length, gather
+
+
+def cent_select(query: torch.Tensor, l1_cent: torch.Tensor, block_ids: torch.Tensor, block_table: torch.Tensor,
+                seq_len: torch.Tensor, *, k: int = 64, sink_recent: bool = False, max_pages_cap: bool = False,
+                max_page_num: int = 256, page_size: int = 128
+                ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """(page_position [B,Hq,256] i32, page_position_length [B,Hq,8] i32, max_page_position_length [B,8] i64)
+    with B = seq_len.shape[0] (add_custom.py:89-93; binding add_custom.cpp:979-1008)."""
+    _abi.require_gpu(query, l1_cent, block_ids, block_table, seq_len)
+    B, Hq = seq_len.shape[0], query.shape[1]
+    dev = query.device
+    pos = torch.empty((B, Hq, int(max_page_num)), dtype=torch.int32, device=dev)
+    length = torch.empty((B, Hq, 8), dtype=torch.int32, device=dev)
+    max_len = torch.empty((B, 8), dtype=torch.int64, device=dev)
+    _set_knobs(k, sink_recent, max_pages_cap, page_size)
+    descs = [_abi.to_acl(t) for t in (query, l1_cent, block_ids, block_table, seq_len)]
+    descs += [None]  # importance: allocated but never read by the reference (add_custom.cpp:995)
+    descs += [_abi.to_acl(t) for t in (pos, length, max_len)]
+    try:
+        _abi.run(_abi.aclnnCentSelectGetWorkspaceSize, _abi.aclnnCentSelect, descs, dev, "aclnnCentSelect")
+    finally:
+        _destroy(descs)
+    return pos, length, max_len
+
+
+def _seq_lengths_arg(actual_seq_lengths, device):
+    """Host list / CPU tensor -> aclIntArray; a GPU tensor is handed over as a device pointer so the
+    call does not synchronise (the reference copies it to the host, add_custom.cpp:113)."""
+    if isinstance(actual_seq_lengths, torch.Tensor) and actual_seq_lengths.is_cuda and actual_seq_lengths.numel() > 0:
+        dev_lengths = actual_seq_lengths.to(torch.int64).contiguous()
+        _abi.check(_abi.spfaSetActualSeqLengthsDevice(dev_lengths.data_ptr(), dev_lengths.numel()),
+                   "spfaSetActualSeqLengthsDevice")
+        return None, dev_lengths
+    return _abi.to_int_array(actual_seq_lengths), None
+
+
+def sparse_paged_attention(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, pse_shift: torch.Tensor,
+                           attention_mask: torch.Tensor, actual_seq_lengths, dequant_scale1: torch.Tensor,
+                           quant_scale1: torch.Tensor, dequant_scale2: torch.Tensor, quant_scale2: torch.Tensor,
+                           quant_offset2: torch.Tensor, antiquant_scale: torch.Tensor,
+                           antiquant_offset: torch.Tensor, blocktable: torch.Tensor, kv_padding_size: torch.Tensor,
+                           blockposition: torch.Tensor, num_heads: int, scale_value: float, input_layout: str,
+                           num_key_value_heads: int, block_size: int, inner_precise: int,
+                           *, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """Decode attention over the pages listed in blockposition (add_custom.py:41-75; binding
+    sparse_paged_attention_impl_npu wraps key/value into one-tensor lists and returns a tensor shaped
+    like query).  out_dtype=torch.float32 (extra) returns the un-rounded result."""
+    _abi.require_gpu(query, key, value, blocktable, blockposition)
+    dev = query.device
+    out = torch.empty(query.shape, dtype=out_dtype or query.dtype, device=dev)
+    seq_arr, dev_lengths = _seq_lengths_arg(actual_seq_lengths, dev)
+    tens = [_abi.to_acl(t) for t in (query,)]
+    kl, vl = _abi.to_acl_list([key]), _abi.to_acl_list([value])
+    opt = [_abi.to_acl(t) for t in (pse_shift, attention_mask)]
+    quant = [_abi.to_acl(t) for t in (dequant_scale1, quant_scale1, dequant_scale2, quant_scale2, quant_offset2,
+                                      antiquant_scale, antiquant_offset, blocktable, kv_padding_size, blockposition)]
+    out_d = _abi.to_acl(out)
+    args = tens + [kl, vl] + opt + [seq_arr] + quant + [
+        int(num_heads), float(scale_value), str(input_layout).encode(), int(num_key_value_heads), int(block_size),
+        int(inner_precise), out_d]
+    try:
+        _abi.run(_abi.aclnnSparsePagedAttentionGetWorkspaceSize, _abi.aclnnSparsePagedAttention, args, dev,
+                 "aclnnSparsePagedAttention")
+    finally:
+        _abi.spfaSetActualSeqLengthsDevice(None, 0)
+        _destroy(tens + opt + quant + [out_d], [kl, vl], [seq_arr])
+    if dev_lengths is not None:
+        dev_lengths.record_stream(torch.cuda.current_stream(dev))
+    return out
+
+
+def sparse_paged_fusion_attention(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor,
+                                  pse_shift: torch.Tensor, attention_mask: torch.Tensor, actual_seq_lengths,
+                                  dequant_scale1: torch.Tensor, quant_scale1: torch.Tensor,
+                                  dequant_scale2: torch.Tensor, quant_scale2: torch.Tensor,
+                                  quant_offset2: torch.Tensor, antiquant_scale: torch.Tensor,
+                                  antiquant_offset: torch.Tensor, blocktable: torch.Tensor,
+                                  kv_padding_size: torch.Tensor, l1_cent: torch.Tensor, block_ids: torch.Tensor,
+                                  total_seq_len: torch.Tensor, block_position: torch.Tensor,
+                                  page_position_length: torch.Tensor, max_page_position_length: torch.Tensor,
+                                  num_heads: int, scale_value: float, input_layout: str, num_key_value_heads: int,
+                                  block_size: int, inner_precise: int, *, k: int = 64, sink_recent: bool = False,
+                                  max_pages_cap: bool = False, out_dtype: Optional[torch.dtype] = None
+                                  ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """CentSelect + sparse paged attention in one kernel launch (add_custom.py:96-135).  Returns
+    (attention_out, block_position, max_page_position_length) — the 3-tuple of the registered schema
+    (extension/csrc/registration.cpp:50-56); block_position, page_position_length and
+    max_page_position_length are filled in place.  actual_seq_lengths is only a tiling hint in the
+    reference (sparse_paged_fusion_attention.cpp:68) and is ignored."""
+    _abi.require_gpu(query, key, value, blocktable, l1_cent, block_ids, total_seq_len)
+    dev = query.device
+    out = torch.empty(query.shape, dtype=out_dtype or query.dtype, device=dev)
+    _set_knobs(k, sink_recent, max_pages_cap)
+    tens = [_abi.to_acl(query)]
+    kl, vl = _abi.to_acl_list([key]), _abi.to_acl_list([value])
+    mid = [_abi.to_acl(t) for t in (pse_shift, attention_mask)]
+    rest = [_abi.to_acl(t) for t in (dequant_scale1, quant_scale1, dequant_scale2, quant_scale2, quant_offset2,
+                                     antiquant_scale, antiquant_offset, blocktable, kv_padding_size, l1_cent,
+                                     block_ids, total_seq_len)]
+    outs = [_abi.to_acl(t) for t in (block_position, page_position_length, max_page_position_length, out)]
+    args = tens + [kl, vl] + mid + [None] + rest + [
+        int(num_heads), float(scale_value), str(input_layout).encode(), int(num_key_value_heads), int(block_size),
+        int(inner_precise)] + outs
+    try:
+        _abi.run(_abi.aclnnSparsePagedFusionAttentionGetWorkspaceSize, _abi.aclnnSparsePagedFusionAttention, args,
+                 dev, "aclnnSparsePagedFusionAttention")
+    finally:
+        _destroy(tens + mid + rest + outs, [kl, vl])
+    return out, block_position, max_page_position_length

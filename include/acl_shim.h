@@ -1,0 +1,109 @@
+/*
+ * Descriptor shim for the aclnn-style two-phase C-ABI on MI355X (HIP).
+ *
+ * The reference's bindings describe every operand with opaque CANN descriptors before calling
+ * aclnn<Op>GetWorkspaceSize / aclnn<Op> (extension/csrc/add_custom.cpp:30-118,836-895;
+ * dlsym'd prototypes in extension/csrc/pytorch_npu_helper.hpp:47-72).  This header declares the
+ * same entry points with the same argument order, enum values and ownership rules so those call
+ * sites bind unchanged; device pointers are HIP device pointers and aclrtStream is a hipStream_t.
+ *
+ * Ownership (add_custom.cpp:906-929): the caller owns tensor memory and descriptors and may destroy
+ * descriptors right after the exec call returns; GetWorkspaceSize therefore copies shapes, strides,
+ * pointers and aclIntArray contents into the executor.  The executor is consumed by the exec call
+ * unless aclSetAclOpExecutorRepeatable was called on it, in which case the caller destroys it with
+ * aclDestroyAclOpExecutor (add_custom.cpp:847,929).
+ */
+#ifndef SPFA_ACL_SHIM_H_
+#define SPFA_ACL_SHIM_H_
+
+#include <stdbool.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPFA_API __attribute__((visibility("default")))
+
+typedef int aclnnStatus;   /* 0 = success */
+typedef void* aclrtStream; /* hipStream_t */
+
+/* status codes (subset of CANN's aclnn error space) */
+#define ACLNN_SUCCESS 0
+#define ACLNN_ERR_PARAM_NULLPTR 161001
+#define ACLNN_ERR_PARAM_INVALID 161002
+#define ACLNN_ERR_RUNTIME_ERROR 361001
+#define ACLNN_ERR_INNER 561000
+
+/* values of CANN's aclDataType / aclFormat that the reference's binding uses
+ * (add_custom.cpp:41-70, :74 ACL_FORMAT_ND) */
+typedef enum {
+    ACL_DT_UNDEFINED = -1,
+    ACL_FLOAT = 0,
+    ACL_FLOAT16 = 1,
+    ACL_INT8 = 2,
+    ACL_INT32 = 3,
+    ACL_UINT8 = 4,
+    ACL_INT16 = 6,
+    ACL_UINT16 = 7,
+    ACL_UINT32 = 8,
+    ACL_INT64 = 9,
+    ACL_UINT64 = 10,
+    ACL_DOUBLE = 11,
+    ACL_BOOL = 12,
+    ACL_BF16 = 27
+} aclDataType;
+
+typedef enum { ACL_FORMAT_UNDEFINED = -1, ACL_FORMAT_NCHW = 0, ACL_FORMAT_NHWC = 1, ACL_FORMAT_ND = 2 } aclFormat;
+
+typedef struct aclTensor aclTensor;
+typedef struct aclTensorList aclTensorList;
+typedef struct aclIntArray aclIntArray;
+typedef struct aclOpExecutor aclOpExecutor;
+
+/* pytorch_npu_helper.hpp:55-58 */
+SPFA_API aclTensor* aclCreateTensor(const int64_t* viewDims, uint64_t viewDimsNum, aclDataType dataType,
+                                    const int64_t* stride, int64_t offset, aclFormat format,
+                                    const int64_t* storageDims, uint64_t storageDimsNum, void* tensorData);
+SPFA_API aclnnStatus aclDestroyTensor(const aclTensor* tensor);
+/* takes ownership of the listed tensors, like CANN (add_custom.cpp:101,907-908) */
+SPFA_API aclTensorList* aclCreateTensorList(const aclTensor* const* value, uint64_t size);
+SPFA_API aclnnStatus aclDestroyTensorList(const aclTensorList* list);
+/* copies the host values (add_custom.cpp:113-117) */
+SPFA_API aclIntArray* aclCreateIntArray(const int64_t* value, uint64_t size);
+SPFA_API aclnnStatus aclDestroyIntArray(const aclIntArray* array);
+
+SPFA_API aclnnStatus aclSetAclOpExecutorRepeatable(aclOpExecutor* executor);
+SPFA_API aclnnStatus aclDestroyAclOpExecutor(aclOpExecutor* executor);
+/* thread-local text of the most recent failure (add_custom.cpp:860) */
+SPFA_API const char* aclGetRecentErrMsg(void);
+
+/* Looked up but null-tolerated by the reference's dispatch macro
+ * (pytorch_npu_helper.hpp:727-748,785-798); provided as no-ops. */
+SPFA_API int InitHugeMemThreadLocal(void* arg, bool sync);
+SPFA_API void UnInitHugeMemThreadLocal(void* arg, bool sync);
+SPFA_API void ReleaseHugeMem(void* arg, bool sync);
+
+/*
+ * Extensions (no counterpart in the reference): per-thread knobs read by the next
+ * aclnn<Op>GetWorkspaceSize on the calling thread.  The reference hard-codes these
+ * (k: add_custom.cpp:940, cent_select_tiling.cpp:58, ..._tiling.cc:1603; sink/recent pages and the
+ * pageLen/8 cap: cent_select.cpp:218,350-362,410-414).  Defaults: k = 64, sink_recent = 0,
+ * cap_pages = 0 (the reference's Python/CPU path).
+ */
+SPFA_API aclnnStatus spfaSetTopK(int64_t k);
+SPFA_API aclnnStatus spfaSetSinkRecent(int enable);
+SPFA_API aclnnStatus spfaSetPageCap(int enable);
+/* page size of the two ops without a blockSize attribute (CentSelect, SelectPosition); the reference
+ * compiles in 128 (cent_select.cpp:17, select_position.cpp:112).  Default 128. */
+SPFA_API aclnnStatus spfaSetPageSize(int64_t pageSize);
+/* One-shot: the next aclnnSparsePagedAttentionGetWorkspaceSize on this thread reads actual_seq_lengths
+ * from this DEVICE array of n int64 instead of the host aclIntArray (the reference's binding copies a
+ * device tensor to the host first, add_custom.cpp:105-118). */
+SPFA_API aclnnStatus spfaSetActualSeqLengthsDevice(const int64_t* deviceLengths, int64_t n);
+SPFA_API const char* spfaVersion(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPFA_ACL_SHIM_H_ */

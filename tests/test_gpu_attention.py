@@ -1,0 +1,256 @@
+"""GPU parity (through the C-ABI) of sparse_paged_attention and sparse_paged_fusion_attention.
+
+The reference has no CPU attention; the oracle restates the kernel arithmetic (oracle/ref.py) and is
+pinned here by the reference's constant-V known-answer construction (tests/ifa_v5_case.py:584-765),
+the dense-equivalence identity and the fused == separate identity
+(src/transformer/sparse_paged_fusion_attention/test/fused_ifa_v5_case.py:215-276).
+Tolerance: 1e-3 relative on attention_out (BASELINE north_star), measured on the float32 output of
+the kernel; the fp16 / bf16 outputs must equal that float32 result rounded once.
+"""
+import numpy as np
+import pytest
+import torch
+
+import datagen
+import parity
+from oracle import ref
+
+pytestmark = pytest.mark.gpu
+
+SENT = 0x7FFFFFFF
+TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def H():
+    import gpu_helpers
+    return gpu_helpers
+
+
+def _kat(H, layout, bs, Hq, Hkv, D=128, pages_per_head=6, n_blocks=64, head_delta=0.001, B=2):
+    """Selected pages hold head-specific constants, everything else 9.9: the exact answer is the
+    head's constant whatever the softmax weights are (tests/ifa_v5_case.py:634-691)."""
+    shape = (n_blocks, bs, Hkv, D) if layout == "BSH" else (n_blocks, Hkv, bs, D)
+    k = np.full(shape, 9.9, np.float16)
+    v = np.full(shape, 9.9, np.float16)
+    table = np.full((B, Hkv * pages_per_head), SENT, np.int32)
+    pos = np.full((B, Hkv, pages_per_head + 3), SENT, np.int32)
+    vals = []
+    slot = 0
+    for h in range(Hkv):
+        blocks = [((h * 3) % n_blocks + 2 * i) % n_blocks for i in range(pages_per_head)]
+        val = np.float16(0.1 + h * head_delta)
+        vals.append(float(val))
+        for i, blk in enumerate(blocks):
+            if layout == "BSH":
+                k[blk, :, h, :] = val
+                v[blk, :, h, :] = val
+            else:
+                k[blk, h] = val
+                v[blk, h] = val
+            table[:, slot] = blk
+            pos[:, h, i] = slot
+            slot += 1
+    q = np.full((B, Hq, D), 0.1, np.float16)
+    out = H.call_attention(H.dev(q), H.dev(k), H.dev(v), H.dev(table), H.dev(pos),
+                           torch.tensor([pages_per_head * bs], dtype=torch.int64), Hq, Hkv, 1.0, bs)
+    out = H.f32(out)
+    G = Hq // Hkv
+    for h in range(Hq):
+        assert np.allclose(out[:, h], vals[h // G], rtol=1e-3, atol=0), (h, out[0, h, :4], vals[h // G])
+    assert not (np.abs(out - 9.9) < 1.0).any()          # tests/ifa_v5_case.py:751
+
+
+@pytest.mark.parametrize("layout,bs,Hq,Hkv", [("BSH", 128, 8, 8), ("BNSD", 128, 8, 8), ("BSH", 16, 8, 8),
+                                              ("BNSD", 16, 4, 4), ("BSH", 128, 8, 2), ("BSH", 64, 16, 4)])
+def test_known_answer_constant_v(H, layout, bs, Hq, Hkv):
+    _kat(H, layout, bs, Hq, Hkv)
+
+
+def _random_lists(rng, B, rows, max_page, P, lo, hi):
+    pos = np.full((B, rows, P), SENT, np.int32)
+    for b in range(B):
+        for r in range(rows):
+            n = int(rng.integers(lo, hi + 1))
+            pos[b, r, :n] = np.sort(rng.choice(max_page, size=n, replace=False))
+    return pos
+
+
+@pytest.mark.parametrize("dtype,layout,Hq,Hkv,rows,D,bs,seq_mode", [
+    ("f16", "BSH", 8, 8, "kv", 128, 128, "none"),
+    ("f16", "BSH", 8, 2, "kv", 128, 128, "uniform"),
+    ("f16", "BSH", 8, 2, "q", 128, 128, "ragged"),
+    ("f16", "BNSD", 4, 4, "q", 128, 16, "ragged"),
+    ("bf16", "BSH", 8, 2, "kv", 128, 128, "ragged"),
+    ("bf16", "BNSD", 16, 2, "kv", 64, 32, "uniform"),
+    ("f16", "BSH", 4, 4, "kv", 64, 128, "device"),
+    ("f16", "BSH", 4, 1, "kv", 256, 64, "none"),
+    ("f16", "BSH", 32, 2, "kv", 128, 128, "ragged"),     # G = 16: two passes of 8 heads
+])
+def test_attention_vs_oracle(H, dtype, layout, Hq, Hkv, rows, D, bs, seq_mode):
+    rng = datagen.rng_for(1234 + Hq * 7 + D)
+    B, n_blocks, max_page, P = 3, 40, 24, 12
+    tdt = torch.float16 if dtype == "f16" else torch.bfloat16
+    q = datagen.ref_rand_f16(rng, (B, Hq, D))
+    k, v = datagen.kv_case(5, n_blocks, bs, Hkv, D, layout, dist="randn")
+    if dtype == "bf16":   # make every value exactly representable in bf16
+        q, k, v = (ref.round_to_bf16(x.astype(np.float32)) for x in (q, k, v))
+    table = rng.integers(0, n_blocks, size=(B + 2, max_page)).astype(np.int32)
+    R = Hq if rows == "q" else Hkv
+    pos = _random_lists(rng, B, R, max_page, P, 1, P - 2)
+    pos[0, 0, :] = SENT                                     # a head with an empty list -> zeros
+    act_host, act_arg = None, torch.empty(0, dtype=torch.int64)
+    if seq_mode == "uniform":
+        act_host = [5 * bs - 3] * B
+        act_arg = [5 * bs - 3]
+    elif seq_mode in ("ragged", "device"):
+        act_host = [int(x) for x in rng.integers(1, P * bs, size=B)]
+        act_arg = torch.tensor(act_host, dtype=torch.int64)
+        if seq_mode == "device":
+            act_arg = act_arg.to(H.DEV)
+    scale = 1.0 / np.sqrt(D)
+    want = ref.sparse_paged_attention(q, k, v, table, pos, act_host, Hq, Hkv, scale, bs, layout)
+    qd, kd, vd = H.dev(q, tdt), H.dev(k, tdt), H.dev(v, tdt)
+    out32 = H.f32(H.call_attention(qd, kd, vd, H.dev(table), H.dev(pos), act_arg, Hq, Hkv, scale, bs,
+                                   out_dtype=torch.float32))
+    err = float(parity.rel_err(out32, want).max())
+    assert err <= TOL, f"max rel err {err:.3e}"
+    G = Hq // Hkv
+    assert (out32[0, :(G if rows == "kv" else 1)] == 0).all()           # empty list -> zeros
+    out = H.call_attention(qd, kd, vd, H.dev(table), H.dev(pos), act_arg, Hq, Hkv, scale, bs)
+    assert out.dtype == tdt and out.shape == qd.shape
+    assert torch.equal(out.cpu(), torch.from_numpy(out32).to(tdt))      # one rounding of the fp32 result
+    # reference-numerics mode of the oracle (online softmax, P rounded to the KV dtype) agrees too
+    want2 = ref.sparse_paged_attention(q, k, v, table, pos, act_host, Hq, Hkv, scale, bs, layout,
+                                       exact=False, p_round=dtype)
+    # (P rounding costs up to 2^-11 / 2^-8 per term; with zero-mean V compare against the row scale)
+    tol2 = 2e-3 if dtype == "f16" else 1.5e-2
+    dev2 = float(np.abs(want2 - want).max() / np.abs(want).max())
+    assert dev2 <= tol2, dev2
+
+
+def test_dense_equivalence_vs_torch_sdpa(H):
+    """block_position[b,h,j] = j turns the op into ordinary paged attention
+    (tests/ifa_v5_case_tkp.py:370-379 uses the identity mapping)."""
+    rng = datagen.rng_for(99)
+    B, Hq, Hkv, D, bs, n_pages = 2, 8, 2, 128, 128, 5
+    q = datagen.ref_rand_f16(rng, (B, Hq, D))
+    k, v = datagen.kv_case(9, B * n_pages, bs, Hkv, D, "BSH", dist="randn")
+    table = np.arange(B * n_pages, dtype=np.int32).reshape(B, n_pages)
+    pos = np.tile(np.arange(n_pages, dtype=np.int32), (B, Hkv, 1))
+    seq = n_pages * bs - 37
+    out = H.f32(H.call_attention(H.dev(q), H.dev(k), H.dev(v), H.dev(table), H.dev(pos), [seq], Hq, Hkv,
+                                 D ** -0.5, bs, out_dtype=torch.float32))
+    kk = torch.from_numpy(k.astype(np.float32)).reshape(B, n_pages * bs, Hkv, D)[:, :seq]
+    vv = torch.from_numpy(v.astype(np.float32)).reshape(B, n_pages * bs, Hkv, D)[:, :seq]
+    kk = kk.permute(0, 2, 1, 3).repeat_interleave(Hq // Hkv, dim=1)
+    vv = vv.permute(0, 2, 1, 3).repeat_interleave(Hq // Hkv, dim=1)
+    qq = torch.from_numpy(q.astype(np.float32)).unsqueeze(2)
+    want = torch.nn.functional.scaled_dot_product_attention(qq, kk, vv).squeeze(2).numpy()
+    assert float(parity.rel_err(out, want).max()) <= TOL
+
+
+def _fusion_case(seed, B, Hq, Hkv, D, C, seq_lens, kv_page_len, max_page, bs, kv="f16", q_extra=0):
+    q, l1 = datagen.cent_case(seed, B + q_extra, Hq, Hkv, D, C, grid=True)
+    ids, table, seq = datagen.page_case(seed, Hkv, C, kv_page_len, B + 1, max_page, seq_lens)
+    k, v = datagen.kv_case(seed, kv_page_len, bs, Hkv, D, "BSH", dist="randn", dtype="i8" if kv == "i8" else "f16")
+    return q, l1, ids, table, seq, k, v
+
+
+@pytest.mark.parametrize("Hq,Hkv,D,C,topk,seq_lens,kvdt", [
+    (8, 2, 128, 256, 8, [4000, 32 * 128, 129, 77], "f16"),
+    (4, 4, 128, 512, 16, [9000, 5 * 128, 128 * 60], "f16"),
+    (8, 8, 64, 128, 8, [3000, 1, 2500], "f16"),
+    (8, 2, 128, 256, 8, [4000, 32 * 128, 129], "bf16"),
+    (16, 1, 128, 256, 4, [6000, 999], "f16"),             # G = 16
+])
+def test_fusion_vs_oracle_and_separate(H, Hq, Hkv, D, C, topk, seq_lens, kvdt):
+    import custom_ops
+    B, bs, kv_page_len, max_page = len(seq_lens), 128, 96, 80
+    q, l1, ids, table, seq, k, v = _fusion_case(41 + Hq, B, Hq, Hkv, D, C, seq_lens, kv_page_len, max_page, bs, q_extra=1)
+    tdt = torch.float16 if kvdt == "f16" else torch.bfloat16
+    if kvdt == "bf16":
+        k, v = (ref.round_to_bf16(x.astype(np.float32)) for x in (k, v))
+    scale = D ** -0.5
+    want, wpos, wlen, wmax = ref.sparse_paged_fusion_attention(q, k, v, table, l1, ids, seq, Hq, Hkv, scale, bs, topk, 256)
+    qd, kd, vd, l1d = H.dev(q, tdt), H.dev(k, tdt), H.dev(v, tdt), H.dev(l1, tdt)
+    td, idsd, seqd = H.dev(table), H.dev(ids), H.dev(seq)
+    out, pos, plen, pmax = H.call_fusion(qd, kd, vd, td, l1d, idsd, seqd, Hq, Hkv, scale, bs, topk,
+                                         out_dtype=torch.float32)
+    assert np.array_equal(pos.cpu().numpy(), wpos)                     # bit-exact page_position
+    assert np.array_equal(plen.cpu().numpy(), wlen)
+    assert np.array_equal(pmax.cpu().numpy(), wmax)
+    out = H.f32(out)
+    err = float(parity.rel_err(out[:B], want).max())
+    assert err <= TOL, f"max rel err {err:.3e}"
+    # fused == separate (fused_ifa_v5_case.py:215-276)
+    spos, slen, smax = custom_ops.cent_select(qd, l1d, idsd, td, seqd, k=topk)
+    assert torch.equal(spos, pos) and torch.equal(slen, plen) and torch.equal(smax, pmax)
+    if all(s % bs == 0 for s in seq_lens):
+        sep = H.f32(H.call_attention(qd[:B], kd, vd, td, spos, smax[:, 0].contiguous(), Hq, Hkv, scale, bs,
+                                     out_dtype=torch.float32))
+        assert float(parity.rel_err(out[:B], sep).max()) <= TOL
+    # drop-in dtype
+    out16, _, _, _ = H.call_fusion(qd, kd, vd, td, l1d, idsd, seqd, Hq, Hkv, scale, bs, topk)
+    assert out16.dtype == tdt
+    assert torch.equal(out16[:B].cpu(), torch.from_numpy(out[:B]).to(tdt))
+
+
+def test_fusion_page_multiple_equals_separate(H):
+    """All lengths multiples of the page size: fused output == cent_select + sparse_paged_attention."""
+    import custom_ops
+    Hq, Hkv, D, C, topk, bs = 8, 2, 128, 256, 8, 128
+    seq_lens = [40 * 128, 64 * 128]
+    q, l1, ids, table, seq, k, v = _fusion_case(7, 2, Hq, Hkv, D, C, seq_lens, 96, 80, bs)
+    qd, kd, vd, l1d, td, idsd, seqd = (H.dev(x) for x in (q, k, v, l1, table, ids, seq))
+    out, pos, plen, pmax = H.call_fusion(qd, kd, vd, td, l1d, idsd, seqd, Hq, Hkv, 1.0, bs, topk,
+                                         out_dtype=torch.float32)
+    spos, slen, smax = custom_ops.cent_select(qd, l1d, idsd, td, seqd, k=topk)
+    assert torch.equal(spos, pos)
+    sep = H.call_attention(qd, kd, vd, td, spos, smax[:, 0].contiguous(), Hq, Hkv, 1.0, bs, out_dtype=torch.float32)
+    assert float(parity.rel_err(H.f32(out), H.f32(sep)).max()) <= TOL
+
+
+@pytest.mark.parametrize("Hq,Hkv,with_offset", [(8, 2, True), (4, 4, False), (8, 1, True)])
+def test_int8_kv_vs_oracle(H, Hq, Hkv, with_offset):
+    """antiquant path: K_f = (K_i8 + off_k) * scale_k, V_f = (V_i8 + off_v) * scale_v, per channel."""
+    D, C, topk, bs = 128, 256, 8, 128
+    seq_lens = [4000, 20 * 128, 300]
+    B = len(seq_lens)
+    q, l1, ids, table, seq, k, v = _fusion_case(3 + Hq, B, Hq, Hkv, D, C, seq_lens, 96, 80, bs, kv="i8")
+    a_s, a_o = datagen.antiquant_case(5, Hkv, D, with_offset)
+    scale = D ** -0.5
+    want, wpos, wlen, wmax = ref.sparse_paged_fusion_attention(
+        q, k, v, table, l1, ids, seq, Hq, Hkv, scale, bs, topk, 256,
+        antiquant_scale=a_s.astype(np.float32), antiquant_offset=None if a_o is None else a_o.astype(np.float32))
+    qd, l1d, td, idsd, seqd = (H.dev(x) for x in (q, l1, table, ids, seq))
+    kd, vd = H.dev(k), H.dev(v)
+    asd = H.dev(a_s)
+    aod = H.dev(a_o) if a_o is not None else None
+    out, pos, plen, pmax = H.call_fusion(qd, kd, vd, td, l1d, idsd, seqd, Hq, Hkv, scale, bs, topk,
+                                         antiq_scale=asd, antiq_offset=aod, out_dtype=torch.float32)
+    assert np.array_equal(pos.cpu().numpy(), wpos)
+    err = float(parity.rel_err(H.f32(out), want).max())
+    assert err <= TOL, f"max rel err {err:.3e}"
+    # standalone op on the same lists
+    sep = H.call_attention(qd, kd, vd, td, pos, pmax[:, 0].contiguous() * 0 + 10 ** 9, Hq, Hkv, scale, bs,
+                           antiq_scale=asd, antiq_offset=aod, out_dtype=torch.float32)
+    full = all(s % bs == 0 for s in seq_lens)
+    if full:
+        assert float(parity.rel_err(H.f32(sep), want).max()) <= TOL
+
+
+def test_attention_abi_errors(H):
+    from custom_ops._abi import AclError
+    q = H.dev(np.zeros((1, 4, 128), np.float16))
+    kv = H.dev(np.zeros((4, 128, 4, 128), np.float16))
+    table = H.dev(np.zeros((1, 4), np.int32))
+    pos = H.dev(np.zeros((1, 4, 4), np.int32))
+    with pytest.raises(AclError, match="blockSize"):
+        H.call_attention(q, kv, kv, table, pos, [128], 4, 4, 1.0, 100)
+    with pytest.raises(AclError, match="antiquant"):
+        H.call_attention(q, kv, kv, table, pos, [128], 4, 4, 1.0, 128, antiq_scale=H.dev(np.ones((2, 4, 128), np.float16)))
+    with pytest.raises(AclError, match="int8 KV cache needs"):
+        H.call_attention(q, kv.to(torch.int8), kv.to(torch.int8), table, pos, [128], 4, 4, 1.0, 128)
+    with pytest.raises(AclError, match="blockposition"):
+        H.call_attention(q, kv, kv, table, H.dev(np.zeros((1, 3, 4), np.int32)), [128], 4, 4, 1.0, 128)
