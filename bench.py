@@ -1,0 +1,264 @@
+#!/usr/bin/env python3
+"""Decode-step benchmark of the fused SparsePagedFusionAttention op on MI355X.
+
+One "step" = one fused-op call for one layer over the whole batch (B decode tokens):
+Q.Cent^T -> top-k -> page selection -> sparse paged attention, one kernel launch.
+Default workload = BASELINE.json configs[2] (the configuration the metric is quoted on):
+B=64 H=32 (MHA) D=128 seqlen=32k C=2048 k=32, fp16 KV in the vLLM BSH layout, block_size 128,
+synthetic inputs in the reference's distributions, a 32 GiB disjoint KV pool (>> the 256 MiB
+Infinity Cache) and "budgeted" block_ids so every head selects pageLen/8 = 32 pages (the reference's
+design point, fused_ifa_v5_case.py:33-34).
+
+    python bench.py [--gpus N --steps K --warmup W]          # N>1: launched under torch.distributed.run
+
+Prints ONE JSON line (rank 0).  `value` = decode tokens/s of the whole job with inputs resident in HBM.
+`roofline` prices the fused kernel against the HBM roofline with ALGORITHMIC bytes of the KV gather
+(sum over (batch, kv head) of |pages selected by the group| * block_size * D * (sizeof K + sizeof V),
+read back from page_position) divided by the kernel's average duration measured with HIP events on the
+launch stream.  `cpu_baseline` times the CPU oracle (oracle/oracle.c, OpenMP) on a bounded sample of the
+same workload on this box's host cores (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "cann-ops-adv-vllm_amd"))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (≈6.3 TB/s is what a streaming copy achieves)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=64, help="sequences per GPU")
+    ap.add_argument("--heads", type=int, default=32)
+    ap.add_argument("--kv-heads", type=int, default=32)
+    ap.add_argument("--head-dim", type=int, default=128)
+    ap.add_argument("--seqlen", type=int, default=32 * 1024)
+    ap.add_argument("--clusters", type=int, default=2048)
+    ap.add_argument("--topk", type=int, default=32)
+    ap.add_argument("--block-size", type=int, default=128)
+    ap.add_argument("--kv", choices=["f16", "bf16", "int8"], default="f16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-batch", type=int, default=8)
+    ap.add_argument("--seed", type=int, default=2024)
+    return ap.parse_args()
+
+
+def build_workload(a, device, B, seed, custom_ops):
+    """Synthetic decode state for B sequences on `device` (all tensors resident in HBM)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    Hq, Hkv, D, C, k, bs = a.heads, a.kv_heads, a.head_dim, a.clusters, a.topk, a.block_size
+    G = Hq // Hkv
+    page_len = (a.seqlen + bs - 1) // bs
+    n_pages = B * page_len
+    qdt = torch.bfloat16 if a.kv == "bf16" else torch.float16
+    eps = 1e-3
+    q = (torch.rand((B, Hq, D), generator=g, device=device) * (1 - eps) + eps).to(qdt)
+    l1 = torch.randn((Hkv, C, D), generator=g, device=device).to(qdt)
+    if a.kv == "int8":
+        key = torch.empty((n_pages, bs, Hkv, D), dtype=torch.int8, device=device)
+        val = torch.empty_like(key)
+        step = max(1, (1 << 30) // (bs * Hkv * D))
+        for i in range(0, n_pages, step):
+            key[i:i + step] = torch.randint(-127, 128, key[i:i + step].shape, generator=g, device=device, dtype=torch.int8)
+            val[i:i + step] = torch.randint(-127, 128, val[i:i + step].shape, generator=g, device=device, dtype=torch.int8)
+        a_scale = (torch.rand((2, Hkv, D), generator=g, device=device) * 0.02 + 0.001).to(qdt)
+        a_off = torch.randn((2, Hkv, D), generator=g, device=device).to(qdt)
+    else:
+        key = torch.empty((n_pages, bs, Hkv, D), dtype=qdt, device=device)
+        val = torch.empty_like(key)
+        step = max(1, (1 << 30) // (bs * Hkv * D * 2))
+        for i in range(0, n_pages, step):
+            key[i:i + step].uniform_(eps, 1.0, generator=g)
+            val[i:i + step].uniform_(eps, 1.0, generator=g)
+        a_scale = a_off = None
+    # disjoint block table: every (sequence, logical page) owns one physical page
+    table = torch.randperm(n_pages, generator=g, device=device).to(torch.int32).reshape(B, page_len)
+    seq = torch.full((B,), a.seqlen, dtype=torch.int32, device=device)
+    # budgeted block_ids: per (sequence, kv head) exactly page_len/8 pages carry a cluster id from the
+    # true top-k of one of the group's q heads, every other page an id outside the group's top-k sets
+    topk = custom_ops.compute_cent(q, l1, k=k).long()                       # [B,Hq,k]
+    member = torch.zeros((B, Hkv, C), dtype=torch.bool, device=device)
+    member.scatter_(2, topk.reshape(B, Hkv, G * k), True)
+    ids = torch.randint(0, C, (B, Hkv, page_len), generator=g, device=device)
+    for _ in range(64):
+        bad = member.gather(2, ids)
+        if not bad.any():
+            break
+        ids = torch.where(bad, torch.randint(0, C, ids.shape, generator=g, device=device), ids)
+    n_sel = max(1, page_len // 8)
+    sel = torch.rand((B, Hkv, page_len), generator=g, device=device).argsort(dim=2)[:, :, :n_sel]   # pages
+    head_of = sel % G                                                        # which q head of the group
+    pick = torch.randint(0, k, sel.shape, generator=g, device=device)
+    tk = topk.reshape(B, Hkv, G, k)
+    chosen = tk.gather(2, head_of.unsqueeze(-1).expand(-1, -1, -1, k)).gather(3, pick.unsqueeze(-1)).squeeze(-1)
+    ids.scatter_(2, sel, chosen)
+    block_ids = torch.zeros((Hkv, n_pages), dtype=torch.int32, device=device)
+    phys = table.long().unsqueeze(1).expand(B, Hkv, page_len)
+    block_ids.scatter_(1, phys.permute(1, 0, 2).reshape(Hkv, -1), ids.permute(1, 0, 2).reshape(Hkv, -1).to(torch.int32))
+    return dict(q=q, l1=l1, key=key, val=val, table=table, seq=seq, block_ids=block_ids, a_scale=a_scale,
+                a_off=a_off, page_len=page_len, n_pages=n_pages)
+
+
+def gather_bytes(pos, plen, Hkv, G, max_page, bs, D, kv_elem):
+    """Algorithmic KV bytes of one launch: pages shared inside a GQA group count once per kv head."""
+    B, Hq, P = pos.shape
+    valid = torch.arange(P, device=pos.device)[None, None, :] < plen[:, :, :1]
+    hit = torch.zeros((B, Hkv, max_page + 1), dtype=torch.bool, device=pos.device)
+    idx = torch.where(valid, pos.long(), torch.full_like(pos, max_page).long()).reshape(B, Hkv, G * P)
+    hit.scatter_(2, idx, True)
+    pages = int(hit[:, :, :max_page].sum().item())
+    return pages, pages * bs * D * kv_elem * 2
+
+
+def cpu_baseline(a, wl, custom_ops, plan_args):
+    """Time the CPU oracle (C/OpenMP port) on the first `cpu_sample_batch` sequences of the workload."""
+    from oracle import cport
+    Bs = min(a.cpu_sample_batch, wl["q"].shape[0])
+    page_len = wl["page_len"]
+    # compact the sample's pages into a small pool so only ~Bs*page_len pages cross PCIe
+    phys = wl["table"][:Bs].reshape(-1).long()
+    key = wl["key"][phys].cpu().numpy() if a.kv == "int8" else wl["key"][phys].cpu().view(torch.int16).numpy().view(np.uint16)
+    val = wl["val"][phys].cpu().numpy() if a.kv == "int8" else wl["val"][phys].cpu().view(torch.int16).numpy().view(np.uint16)
+    table = np.arange(Bs * page_len, dtype=np.int32).reshape(Bs, page_len)
+    ids = wl["block_ids"][:, phys].cpu().numpy()
+    as16 = lambda t: t.cpu().view(torch.int16).numpy().view(np.uint16)
+    dt = "bf16" if a.kv == "bf16" else "f16"
+    kw = dict(kv_dt="i8" if a.kv == "int8" else dt, dt=dt)
+    if a.kv == "int8":
+        kw.update(antiq_scale=as16(wl["a_scale"]), antiq_offset=as16(wl["a_off"]))
+    q, l1 = as16(wl["q"][:Bs]), as16(wl["l1"])
+    seq = wl["seq"][:Bs].cpu().numpy()
+    scale = a.head_dim ** -0.5
+    run = lambda: cport.fusion(q, key, val, table, l1, ids, seq, a.heads, a.kv_heads, scale, a.block_size, a.topk,
+                               256, **kw)
+    out, pos, len8, max8 = run()
+    # the sample doubles as a full-size-shape parity check of the GPU result
+    got = plan_args["out"][:Bs].float().cpu().numpy()
+    gpos = plan_args["pos"][:Bs].cpu().numpy()
+    denom = np.maximum(np.abs(out), 1e-2 * np.abs(out).max())
+    parity = {"page_position_equal": bool(np.array_equal(gpos, pos)),
+              "attention_max_rel_err": float((np.abs(got - out) / denom).max())}
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        run()
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > 12.0 or reps >= 5000:
+            break
+    return {"value": Bs * reps / el, "unit": "tokens/s", "cores": cport.threads(), "kind": "port",
+            "sample": f"first {Bs} of {wl['q'].shape[0]} sequences (same H/D/S/C/k, KV pages compacted to the host), "
+                      f"{reps} reps in {el:.1f}s of oracle/oracle.c (OpenMP)",
+            "ms_per_step_sample": 1e3 * el / reps, "parity_vs_gpu": parity}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    import custom_ops
+    from custom_ops import shard
+
+    B = a.batch                                     # weak scaling: `batch` sequences per GPU
+    wl = build_workload(a, device, B, a.seed + 1000 * rank, custom_ops)
+    Hq, Hkv, D, bs = a.heads, a.kv_heads, a.head_dim, a.block_size
+    pos = torch.empty((B, Hq, 256), dtype=torch.int32, device=device)
+    plen = torch.empty((B, Hq, 8), dtype=torch.int32, device=device)
+    pmax = torch.empty((B, 8), dtype=torch.int64, device=device)
+    plan = custom_ops.PreparedFusion(wl["q"], wl["key"], wl["val"], wl["table"], wl["l1"], wl["block_ids"], wl["seq"],
+                                     pos, plen, pmax, Hq, D ** -0.5, Hkv, bs, antiquant_scale=wl["a_scale"],
+                                     antiquant_offset=wl["a_off"], k=a.topk)
+    reducer = shard.GlobalMaxLength(device) if world > 1 else None
+
+    def step():
+        if reducer is not None:
+            reducer.before_launch()
+        plan.run()
+        if reducer is not None:      # the only collective of the path: global max_page_position_length
+            reducer.submit(pmax)
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(a.steps):
+        step()
+    ev1.record()
+    torch.cuda.synchronize()
+    if reducer is not None:
+        reducer.wait()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / a.steps      # launch-stream events: memset node + fused kernel
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kv_elem = 1 if a.kv == "int8" else 2
+    pages, gbytes = gather_bytes(pos, plen, Hkv, Hq // Hkv, wl["page_len"], bs, D, kv_elem)
+    achieved = gbytes / (kernel_ms * 1e-3) / 1e9
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "traffic.json")   # HBM bytes per launch from rocprofv3 --pmc passes
+    if os.path.exists(tfile):
+        try:
+            rec = json.load(open(tfile))
+            key = f"B{B}_H{Hq}_KV{Hkv}_D{D}_S{a.seqlen}_C{a.clusters}_k{a.topk}_{a.kv}"
+            traffic = rec.get(key, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    result = {
+        "metric": "decode tokens/sec + KV HBM GB/s vs roofline, B=64 H=32 D=128 S=32k k=32",
+        "value": world * B * a.steps / elapsed, "unit": "tokens/s", "n_gpus": world, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": {"f16": "f16", "bf16": "bf16", "int8": "i8"}[a.kv], "data": "synthetic",
+        "config": {"workload": "sparse_paged_fusion_attention decode step (BASELINE configs[2])",
+                   "batch_per_gpu": B, "global_batch": world * B, "heads": Hq, "kv_heads": Hkv, "head_dim": D,
+                   "seq_len": a.seqlen, "clusters": a.clusters, "topk": a.topk, "block_size": bs, "kv_dtype": a.kv,
+                   "kv_layout": "BSH [blocks, block_size, Hkv, D]", "kv_pool_GiB": round(2 * wl["key"].numel() * kv_elem / 2 ** 30, 2),
+                   "pages_selected_per_launch": pages, "parallelism": f"batch-shard x{world}"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": kernel_ms,
+                     "algorithmic_bytes_per_launch": gbytes},
+    }
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        try:
+            result["cpu_baseline"] = cpu_baseline(a, wl, custom_ops, {"out": plan.out, "pos": pos})
+        except Exception as e:   # the GPU number stands on its own; say why the CPU leg is missing
+            result["cpu_baseline"] = {"value": None, "error": repr(e)}
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    plan.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

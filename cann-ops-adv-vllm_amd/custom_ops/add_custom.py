@@ -188,3 +188,59 @@ def sparse_paged_fusion_attention(query: torch.Tensor, key: torch.Tensor, value:
     finally:
         _destroy(tens + mid + rest + outs, [kl, vl])
     return out, block_position, max_page_position_length
+
+
+class PreparedFusion:
+    """Plan once, launch many: keeps the executor of sparse_paged_fusion_attention alive
+    (aclSetAclOpExecutorRepeatable, the pattern of extension/csrc/add_custom.cpp:847,886-895) so a
+    decode loop pays descriptor conversion and validation once.  Tensors are captured by pointer:
+    update their contents in place between launches."""
+
+    def __init__(self, query, key, value, blocktable, l1_cent, block_ids, total_seq_len, block_position,
+                 page_position_length, max_page_position_length, num_heads, scale_value, num_key_value_heads,
+                 block_size, *, antiquant_scale=None, antiquant_offset=None, k=64, sink_recent=False,
+                 max_pages_cap=False, out_dtype=None, input_layout="BNSD"):
+        import ctypes
+        _abi.require_gpu(query, key, value, blocktable, l1_cent, block_ids, total_seq_len)
+        self.device = query.device
+        self.out = torch.empty(query.shape, dtype=out_dtype or query.dtype, device=self.device)
+        self._keep = (query, key, value, blocktable, l1_cent, block_ids, total_seq_len, block_position,
+                      page_position_length, max_page_position_length, antiquant_scale, antiquant_offset)
+        _set_knobs(k, sink_recent, max_pages_cap)
+        tens = [_abi.to_acl(query)]
+        kl, vl = _abi.to_acl_list([key]), _abi.to_acl_list([value])
+        rest = [None] * 5 + [_abi.to_acl(t) for t in (antiquant_scale, antiquant_offset, blocktable)] + [None] + \
+            [_abi.to_acl(t) for t in (l1_cent, block_ids, total_seq_len)]
+        outs = [_abi.to_acl(t) for t in (block_position, page_position_length, max_page_position_length, self.out)]
+        args = tens + [kl, vl, None, None, None] + rest + [
+            int(num_heads), float(scale_value), str(input_layout).encode(), int(num_key_value_heads),
+            int(block_size), 1] + outs
+        ws_size = ctypes.c_uint64(0)
+        self._exec = _abi.T()
+        try:
+            _abi.check(_abi.aclnnSparsePagedFusionAttentionGetWorkspaceSize(*args, ctypes.byref(ws_size),
+                                                                            ctypes.byref(self._exec)),
+                       "aclnnSparsePagedFusionAttentionGetWorkspaceSize")
+        finally:
+            _destroy(tens + rest + outs, [kl, vl])
+        _abi.check(_abi.aclSetAclOpExecutorRepeatable(self._exec), "aclSetAclOpExecutorRepeatable")
+        self._ws = torch.empty(max(int(ws_size.value), 1), dtype=torch.uint8, device=self.device)
+        self._ws_size = int(ws_size.value)
+
+    def run(self) -> torch.Tensor:
+        """Enqueue one fused launch on torch's current stream; returns the (reused) output tensor."""
+        _abi.check(_abi.aclnnSparsePagedFusionAttention(self._ws.data_ptr() if self._ws_size else None,
+                                                        self._ws_size, self._exec, _abi.current_stream(self.device)),
+                   "aclnnSparsePagedFusionAttention")
+        return self.out
+
+    def close(self):
+        if self._exec:
+            _abi.aclDestroyAclOpExecutor(self._exec)
+            self._exec = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
