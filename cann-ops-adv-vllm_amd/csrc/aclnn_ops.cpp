@@ -50,6 +50,7 @@ thread_local int g_page_cap = 0;
 thread_local int64_t g_page_size = 128;   // PAGESIZE of cent_select.cpp:17 / select_position.cpp:112
 thread_local const long long* g_act_seq_dev = nullptr;   // one-shot, consumed by the next attention plan
 thread_local int64_t g_act_seq_dev_n = 0;
+thread_local void* g_debug_buf = nullptr;   // diagnostic stamp buffer (see spfaSetDebugBuffer)
 
 constexpr size_t kMaxLds = 160 * 1024;    // LDS per CU on gfx950
 
@@ -149,7 +150,7 @@ aclnnStatus check_qcent(const aclTensor* query, const aclTensor* l1, int* Hq, in
     *C = (int)l1->dims[1];
     *D = (int)l1->dims[2];
     REQUIRE(*Hkv > 0 && *C > 0, "l1_cent is empty");
-    REQUIRE(*D % 32 == 0 && *D >= 32 && *D <= 256, "head dim %d: must be a multiple of 32 in [32, 256]", *D);
+    REQUIRE(*D == 32 || *D == 64 || *D == 128 || *D == 256, "head dim %d: must be 32, 64, 128 or 256", *D);
     REQUIRE(*C <= 16384, "cluster count %d exceeds 16384", *C);
     (void)Hq;
     return ACLNN_SUCCESS;
@@ -245,6 +246,8 @@ aclnnStatus spfaSetActualSeqLengthsDevice(const int64_t* dev, int64_t n) {
     g_act_seq_dev_n = dev ? n : 0;
     return ACLNN_SUCCESS;
 }
+// Diagnostic only: device buffer of >= grid*16*16 uint64 that -DSPFA_STAMPS builds fill with cycle stamps.
+__attribute__((visibility("default"))) aclnnStatus spfaSetDebugBuffer(void* dev) { g_debug_buf = dev; return ACLNN_SUCCESS; }
 const char* spfaVersion(void) { return "spfa-hip-gfx950 0.1"; }
 
 // ------------------------------------------------------------------------------------------------
@@ -271,7 +274,7 @@ aclnnStatus aclnnComputeCentGetWorkspaceSize(const aclTensor* query, const aclTe
     p.cent = data_ptr(l1Cent);
     p.qk_dtype = to_dtype(query->dtype);
     p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.G = Hq / Hkv; p.D = D; p.C = C; p.k = k;
-    p.Cp = round_up(C, 64);
+    p.Cp = round_up(C, 128);
     p.rows_per_pass = score_rows_per_pass(p.G, p.Cp, 8);
     p.indices = (int32_t*)data_ptr(indicesOut);
     int npow2 = 64;
@@ -382,7 +385,7 @@ aclnnStatus aclnnCentSelectGetWorkspaceSize(const aclTensor* query, const aclTen
     p.cent = data_ptr(l1Cent);
     p.qk_dtype = to_dtype(query->dtype);
     p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.G = Hq / Hkv; p.D = D; p.C = C; p.k = k;
-    p.Cp = round_up(C, 64);
+    p.Cp = round_up(C, 128);
     p.rows_per_pass = score_rows_per_pass(p.G, p.Cp, 8);
     p.block_ids = (const int32_t*)data_ptr(blockIds);
     p.block_table = (const int32_t*)data_ptr(blockTable);
@@ -523,27 +526,36 @@ static aclnnStatus plan_attention(spfa::AttnParams& p, const aclTensor* query, c
     p.scale = (float)scaleValue;
     p.antiq_scale = quant ? data_ptr(antiquantScale) : nullptr;
     p.antiq_offset = (quant && !absent(antiquantOffset)) ? data_ptr(antiquantOffset) : nullptr;
+    p.debug = (unsigned long long*)g_debug_buf;
     return ACLNN_SUCCESS;
 }
+
+constexpr uint64_t kCounterBytes = 256;   // 8 work counters at the start of the workspace, zeroed per launch
 
 static aclnnStatus plan_lds(spfa::AttnParams& p) {
     const bool per_head = (p.mode == 0 && p.pos_rows == p.Hq && p.G > 1);
     p.rows_per_pass = per_head ? 1 : spfa::attention_rows_per_pass(p.G, p.kv_dtype);
-    const int nq = p.rows_per_pass;
-    size_t region = (size_t)4 * nq * (p.D + 2) * 4;                       // cross-wave merge
-    region = std::max(region, (size_t)16 * (size_t)p.max_entries);        // page list
-    size_t cbits = 0, pbits = 0;
+    const size_t nq = (size_t)p.rows_per_pass;
+    auto align16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    size_t off = 0;
+    p.off_keys = (int)off;
     if (p.mode == 1) {
-        REQUIRE((size_t)nq * p.Cp * 4 <= 96 * 1024, "cluster count %d too large for the fused kernel", p.C);
-        region = std::max(region, (size_t)nq * p.Cp * 4);                 // score keys
-        cbits = (size_t)4 * (p.Cp / 32) * 4;
-        pbits = (size_t)nq * ((p.max_page + 63) / 64) * 8;
+        REQUIRE(nq * p.Cp * 4 <= 96 * 1024, "cluster count %d too large for the fused kernel", p.C);
+        off += align16(nq * p.Cp * 4);                                     // score keys (selector wave)
     }
-    region = (region + 15) & ~(size_t)15;
-    p.off_cbits = (int)region;
-    p.off_pbits = (int)(region + cbits);
-    p.off_misc = (int)(region + cbits + pbits);
-    p.lds_bytes = region + cbits + pbits + 16;
+    p.off_cbits = (int)off;
+    if (p.mode == 1) off += align16((size_t)(p.Cp / 32) * 4);              // top-k cluster bitmap
+    p.off_pbits = (int)off;
+    if (p.mode == 1) off += align16(nq * ((p.max_page + 63) / 64) * 8);    // per-head page bitmaps
+    p.off_list = (int)off;
+    off += align16((size_t)2 * p.max_entries * 16);                        // double-buffered page lists
+    p.off_comb = (int)off;
+    off += align16((size_t)2 * 4 * nq * (p.D + 2) * 4);                    // streamer states of two items
+    p.off_qst = (int)off;
+    off += align16((size_t)2 * nq * p.D * 4);                              // pre-scaled q rows
+    p.off_hdr = (int)off;
+    off += 2 * 32;
+    p.lds_bytes = off;
     REQUIRE(p.lds_bytes <= kMaxLds, "page list of %d entries / %d clusters needs %zu bytes of LDS (> %zu)", p.max_entries,
             p.C, p.lds_bytes, kMaxLds);
     return ACLNN_SUCCESS;
@@ -604,11 +616,11 @@ aclnnStatus aclnnSparsePagedAttentionGetWorkspaceSize(
             p.act_seq_uniform = v[0];
         } else {
             e->act_seq.assign(v.begin(), v.begin() + p.B);
-            e->ws_bytes = ((uint64_t)p.B * 8 + 255) & ~255ull;
         }
     }
     st = plan_lds(p);
     if (st != ACLNN_SUCCESS) return bail(st);
+    e->ws_bytes = kCounterBytes + (e->act_seq.empty() ? 0 : (((uint64_t)p.B * 8 + 255) & ~255ull));
     *workspaceSize = e->ws_bytes;
     *executor = e;
     return ACLNN_SUCCESS;
@@ -619,12 +631,15 @@ aclnnStatus aclnnSparsePagedAttention(void* workspace, uint64_t workspaceSize, a
     REQUIRE_PTR(executor, "executor");
     REQUIRE(executor->op == kOpAttention, "executor was not created by aclnnSparsePagedAttentionGetWorkspaceSize");
     spfa::AttnParams p = executor->attn;
-    hipError_t err = hipSuccess;
-    if (!executor->act_seq.empty()) {
-        if (workspace == nullptr || workspaceSize < executor->ws_bytes) {
-            if (!executor->repeatable) delete executor;
-            return fail(ACLNN_ERR_PARAM_INVALID, "workspace of %llu bytes required", (unsigned long long)executor->ws_bytes);
-        }
+    if (workspace == nullptr || workspaceSize < executor->ws_bytes) {
+        const unsigned long long need = executor->ws_bytes;
+        if (!executor->repeatable) delete executor;
+        return fail(ACLNN_ERR_PARAM_INVALID, "workspace of %llu bytes required", need);
+    }
+    p.counters = (unsigned*)workspace;
+    hipError_t err = hipMemsetAsync(workspace, 0, kCounterBytes, (hipStream_t)stream);
+    if (err == hipSuccess && !executor->act_seq.empty()) {
+        void* lengths = (char*)workspace + kCounterBytes;
         // Per-batch lengths travel through the workspace.  A one-shot executor dies when this call
         // returns, so its host copy is handed to the stream and freed there after the copy ran.
         const long long* src = executor->act_seq.data();
@@ -633,7 +648,7 @@ aclnnStatus aclnnSparsePagedAttention(void* workspace, uint64_t workspaceSize, a
             parked = new std::vector<long long>(std::move(executor->act_seq));
             src = parked->data();
         }
-        err = hipMemcpyAsync(workspace, src, (size_t)p.B * 8, hipMemcpyHostToDevice, (hipStream_t)stream);
+        err = hipMemcpyAsync(lengths, src, (size_t)p.B * 8, hipMemcpyHostToDevice, (hipStream_t)stream);
         if (parked) {
             hipError_t e2 = hipLaunchHostFunc((hipStream_t)stream, [](void* v) { delete (std::vector<long long>*)v; }, parked);
             if (e2 != hipSuccess) {   // could not enqueue the release: wait, then free here
@@ -641,7 +656,7 @@ aclnnStatus aclnnSparsePagedAttention(void* workspace, uint64_t workspaceSize, a
                 delete parked;
             }
         }
-        p.act_seq = (const long long*)workspace;
+        p.act_seq = (const long long*)lengths;
     }
     if (err == hipSuccess) err = spfa::launch_attention(p, (hipStream_t)stream);
     return finish(executor, err, "sparse_paged_attention launch");
@@ -687,7 +702,7 @@ aclnnStatus aclnnSparsePagedFusionAttentionGetWorkspaceSize(
     p.cent = data_ptr(l1_cent);
     p.block_ids = (const int32_t*)data_ptr(block_ids);
     p.seq_len = (const int32_t*)data_ptr(total_seq_len);
-    p.C = C; p.Cp = round_up(C, 64); p.k = k; p.kv_page_len = kv_page_len;
+    p.C = C; p.Cp = round_up(C, 128); p.k = k; p.kv_page_len = kv_page_len;
     p.sink_recent = g_sink_recent; p.cap_pages = g_page_cap;
     p.P = max_page;
     if (!absent(block_position)) {
@@ -716,17 +731,25 @@ aclnnStatus aclnnSparsePagedFusionAttentionGetWorkspaceSize(
     p.max_entries = max_page;   // the union of a group's lists never exceeds the logical page count
     st = plan_lds(p);
     if (st != ACLNN_SUCCESS) return bail(st);
-    *workspaceSize = 0;
+    e->ws_bytes = kCounterBytes;
+    *workspaceSize = e->ws_bytes;
     *executor = e;
     return ACLNN_SUCCESS;
 }
 
-aclnnStatus aclnnSparsePagedFusionAttention(void*, uint64_t, aclOpExecutor* executor, const aclrtStream stream) {
+aclnnStatus aclnnSparsePagedFusionAttention(void* workspace, uint64_t workspaceSize, aclOpExecutor* executor,
+                                            const aclrtStream stream) {
     REQUIRE_PTR(executor, "executor");
     REQUIRE(executor->op == kOpFusion, "executor was not created by aclnnSparsePagedFusionAttentionGetWorkspaceSize");
-    const spfa::AttnParams& p = executor->attn;
-    hipError_t err = hipSuccess;
-    if (p.max_page_position_length && p.B > 0)
+    spfa::AttnParams p = executor->attn;
+    if (workspace == nullptr || workspaceSize < executor->ws_bytes) {
+        const unsigned long long need = executor->ws_bytes;
+        if (!executor->repeatable) delete executor;
+        return fail(ACLNN_ERR_PARAM_INVALID, "workspace of %llu bytes required", need);
+    }
+    p.counters = (unsigned*)workspace;
+    hipError_t err = hipMemsetAsync(workspace, 0, kCounterBytes, (hipStream_t)stream);
+    if (err == hipSuccess && p.max_page_position_length && p.B > 0)   // accumulated with atomicMax
         err = hipMemsetAsync(p.max_page_position_length, 0, (size_t)p.B * spfa::kLenPad * 8, (hipStream_t)stream);
     if (err == hipSuccess) err = spfa::launch_attention(p, (hipStream_t)stream);
     return finish(executor, err, "sparse_paged_fusion_attention launch");

@@ -27,6 +27,8 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 namespace spfa {
 namespace {
@@ -36,7 +38,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
-__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+// readfirstlane makes the wave index provably uniform for the compiler: everything derived from it
+// (page cursors, buffer descriptors, loop bounds) then lives in SGPRs and buffer loads need no waterfall loop.
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 __device__ __forceinline__ unsigned long long lanes_below(int lane) { return (1ull << lane) - 1ull; }
 
 // LDS traffic of ONE wave is in order; this only stops the compiler from caching or moving it.
@@ -80,111 +84,175 @@ __device__ __forceinline__ float load_qk_elem(const void* p, int dtype, long lon
 // ------------------------------------------------------------------------------------------------
 // Q.Cent^T for R (<= 16) q heads of one (batch, kv head) -> order keys in LDS [R][Cp]
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void score_rows(const void* q, const void* cent, int dtype, long long q_row0,
-                                           int n2, int R, int D, int C, int Cp, uint32_t* keys) {
-    const int lane = lane_id(), wave = wave_id();
+// WAVES: waves of the workgroup that share the centroid tiles (1: the calling wave alone).
+// KS = D / 32 MFMA k-steps.  All 16 loads of a group of tiles are issued before the first MFMA (no branch
+// sits between them: dtype and KS are template parameters, out-of-range centroids are clamped and masked at
+// the store), so one round trip to L2 brings 16 KiB per wave instead of 1 KiB.
+template <int WAVES, bool BF16, int KS>
+__device__ __forceinline__ void score_rows_impl(const void* q, const void* cent, long long q_row0, int n2, int R,
+                                                int C, int Cp, uint32_t* keys) {
+    constexpr int D = KS * 32;
+    constexpr int TG = 16 / KS;   // tiles per group: TG * KS = 16 loads in flight
+    const int lane = lane_id();
+    const int wave = WAVES == 1 ? 0 : wave_id();
     const int col = lane & 15;   // A: q row of the tile, B: centroid of the tile
     const int kq = lane >> 4;    // which 8-wide slice of the 32-deep k step
-    const int KS = D >> 5;
-    uint4 qa[8];
+    uint4 qa[KS];
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
+    for (int kk = 0; kk < KS; ++kk) {
         qa[kk] = make_uint4(0, 0, 0, 0);
-        if (kk < KS && col < R)
-            qa[kk] = *(const uint4*)((const char*)q + ((q_row0 + col) * D + kk * 32 + kq * 8) * 2);
+        if (col < R) qa[kk] = *(const uint4*)((const char*)q + ((q_row0 + col) * D + kk * 32 + kq * 8) * 2);
     }
-    const char* cbase = (const char*)cent + (long long)n2 * C * D * 2;
-    const int ntiles = Cp >> 4;
-
-    for (int t = wave; t < ntiles; t += 4) {
-        const int c = t * 16 + col;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const char* cbase = (const char*)cent + (long long)n2 * C * D * 2 + kq * 16;
+    const int ntiles = Cp >> 4;   // Cp % 128 == 0: a multiple of every TG
+    for (int t0 = wave * TG; t0 < ntiles; t0 += WAVES * TG) {
+        uint4 bv[TG][KS];
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            if (kk < KS) {
-                uint4 bv = make_uint4(0, 0, 0, 0);
-                if (c < C) bv = *(const uint4*)(cbase + ((long long)c * D + kk * 32 + kq * 8) * 2);
-                if (dtype == kBF16)
+        for (int j = 0; j < TG; ++j) {
+            const int c = min((t0 + j) * 16 + col, C - 1);
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) bv[j][kk] = *(const uint4*)(cbase + ((long long)c * D + kk * 32) * 2);
+        }
+#pragma unroll
+        for (int j = 0; j < TG; ++j) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                if constexpr (BF16)
                     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, qa[kk]),
-                                                                  __builtin_bit_cast(bf16x8, bv), acc, 0, 0, 0);
+                                                                  __builtin_bit_cast(bf16x8, bv[j][kk]), acc, 0, 0, 0);
                 else
                     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, qa[kk]),
-                                                                 __builtin_bit_cast(half8, bv), acc, 0, 0, 0);
+                                                                 __builtin_bit_cast(half8, bv[j][kk]), acc, 0, 0, 0);
             }
-        }
-        // D fragment: row = (lane >> 4) * 4 + r (q head), col = lane & 15 (centroid)
+            // D fragment: row = (lane >> 4) * 4 + r (q head), col = lane & 15 (centroid)
+            const int c = (t0 + j) * 16 + col;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int qr = kq * 4 + r;
-            if (qr < R) keys[qr * Cp + c] = (c < C) ? score_key(acc[r]) : 0u;
+            for (int r = 0; r < 4; ++r) {
+                const int qr = kq * 4 + r;
+                if (qr < R) keys[qr * Cp + c] = (c < C) ? score_key(acc[r]) : 0u;
+            }
         }
     }
 }
 
-// k-th largest key of krow[0..Cp) (Cp % 64 == 0); executed by one full wave.
-__device__ __forceinline__ uint32_t kth_largest_key(const uint32_t* krow, int Cp, int k, int lane) {
+template <int WAVES>
+__device__ __forceinline__ void score_rows(const void* q, const void* cent, int dtype, long long q_row0,
+                                           int n2, int R, int D, int C, int Cp, uint32_t* keys) {
+#define SPFA_SCORE(KS)                                                                              \
+    case KS:                                                                                        \
+        if (dtype == kBF16) score_rows_impl<WAVES, true, KS>(q, cent, q_row0, n2, R, C, Cp, keys);  \
+        else score_rows_impl<WAVES, false, KS>(q, cent, q_row0, n2, R, C, Cp, keys);                \
+        break;
+    switch (D >> 5) {
+        SPFA_SCORE(1)
+        SPFA_SCORE(2)
+        SPFA_SCORE(4)
+        SPFA_SCORE(8)
+    }
+#undef SPFA_SCORE
+}
+
+
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, true); }
+// Sum of v over the 64 lanes (result uniform).
+__device__ __forceinline__ int wave_sum(int v) {
+    v += dpp_i<0x128>(v);   // row_ror 8
+    v += dpp_i<0x124>(v);   // row_ror 4
+    v += dpp_i<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_i<0xB1>(v);    // quad_perm [1,0,3,2]
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+           __builtin_amdgcn_readlane(v, 48);
+}
+
+// k-th largest key by a 32-step bitwise bisection: T grows bit by bit while at least k keys are >= T.
+// Every lane counts its own keys (compare + add-with-carry, no scalar round trip) and the 64 counts are
+// summed once per step.  KeyAt(j) returns this lane's j-th key, j in [0, nj).
+template <typename KeyAt>
+__device__ __forceinline__ uint32_t bisect_kth(KeyAt key_at, int nj, int k) {
     uint32_t T = 0;
-    if (Cp <= 2048) {
-        uint32_t kr[32];
-        const int nj = Cp >> 6;
-#pragma unroll
-        for (int j = 0; j < 32; ++j) kr[j] = (j < nj) ? krow[j * 64 + lane] : 0u;
-        for (int bit = 31; bit >= 0; --bit) {
-            const uint32_t cand = T | (1u << bit);
-            int cnt = 0;
-#pragma unroll
-            for (int j = 0; j < 32; ++j) cnt += __popcll(__ballot(kr[j] >= cand));
-            if (cnt >= k) T = cand;
-        }
-    } else {
-        for (int bit = 31; bit >= 0; --bit) {
-            const uint32_t cand = T | (1u << bit);
-            int cnt = 0;
-            for (int j = lane; j < Cp; j += 64) cnt += __popcll(__ballot(krow[j] >= cand));
-            if (cnt >= k) T = cand;
-        }
+    for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t cand = T | (1u << bit);
+        int c = 0;
+        for (int j = 0; j < nj; ++j) c += (key_at(j) >= cand) ? 1 : 0;
+        if (wave_sum(c) >= k) T = cand;
     }
     return T;
 }
 
+// Walk the top-k of one row (Cp % 64 == 0, executed by one full wave): emit(j, key, take, sel) is called for
+// every 64-key slice j with this lane's key, whether it belongs to the top-k and the slice's ballot.
+// Keys equal to the k-th largest are taken in ascending cluster-id order.
+template <typename Emit>
+__device__ __forceinline__ void topk_walk(const uint32_t* krow, int Cp, int k, int lane, Emit emit) {
+    const int nj = Cp >> 6;
+    auto finish = [&](auto key_at) {
+        const uint32_t T = bisect_kth(key_at, nj, k);
+        int c = 0;
+        for (int j = 0; j < nj; ++j) c += (key_at(j) > T) ? 1 : 0;
+        int need = k - wave_sum(c);   // ties at the threshold, lowest cluster ids first
+        for (int j = 0; j < nj; ++j) {
+            const uint32_t key = key_at(j);
+            const unsigned long long eq = __ballot(key == T);
+            const bool take = (key > T) || (key == T && (int)__popcll(eq & lanes_below(lane)) < need);
+            const unsigned long long sel = __ballot(take);
+            need -= min(need, (int)__popcll(eq));
+            emit(j, key, take, sel);
+        }
+    };
+    if (nj <= 32) {   // C <= 2048: the row lives in registers for all 32 bisection steps
+        uint32_t kr[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) kr[j] = (j < nj) ? krow[j * 64 + lane] : 0u;
+        uint32_t T = 0;
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t cand = T | (1u << bit);
+            int c = 0;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) c += (kr[j] >= cand) ? 1 : 0;   // padding keys are 0 < cand
+            if (wave_sum(c) >= k) T = cand;
+        }
+        int c = 0;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) c += (kr[j] > T) ? 1 : 0;
+        int need = k - wave_sum(c);
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            if (j < nj) {
+                const uint32_t key = kr[j];
+                const unsigned long long eq = __ballot(key == T);
+                const bool take = (key > T) || (key == T && (int)__popcll(eq & lanes_below(lane)) < need);
+                const unsigned long long sel = __ballot(take);
+                need -= min(need, (int)__popcll(eq));
+                emit(j, key, take, sel);
+            }
+        }
+    } else {
+        finish([&](int j) { return krow[j * 64 + lane]; });
+    }
+}
+
 // Top-k of one row as a C-bit bitmap (uint32 words, Cp/32 of them); one full wave.
 __device__ __forceinline__ void topk_bitmap(const uint32_t* krow, int Cp, int k, uint32_t* bits, int lane) {
-    const uint32_t T = kth_largest_key(krow, Cp, k, lane);
-    int n_gt = 0;
-    for (int j = lane; j < Cp; j += 64) n_gt += __popcll(__ballot(krow[j] > T));
-    int need = k - n_gt;   // ties at the threshold, lowest cluster ids first
-    for (int j = lane; j < Cp; j += 64) {
-        const uint32_t key = krow[j];
-        const unsigned long long eq = __ballot(key == T);
-        const bool take = (key > T) || (key == T && __popcll(eq & lanes_below(lane)) < need);
-        const unsigned long long sel = __ballot(take);
-        need -= min(need, (int)__popcll(eq));
+    topk_walk(krow, Cp, k, lane, [&](int j, uint32_t, bool, unsigned long long sel) {
         if (lane == 0) {
-            bits[(j >> 5)] = (uint32_t)sel;
-            bits[(j >> 5) + 1] = (uint32_t)(sel >> 32);
+            bits[2 * j] = (uint32_t)sel;
+            bits[2 * j + 1] = (uint32_t)(sel >> 32);
         }
-    }
+    });
 }
 
 // Top-k of one row, sorted descending (ties: ascending id) -> out[0..k); one full wave.
 // sortbuf: LDS, npow2 (>= k, power of two) uint64 entries owned by this wave.
 __device__ __forceinline__ void topk_sorted(const uint32_t* krow, int Cp, int k, int npow2,
                                             unsigned long long* sortbuf, int32_t* out, int lane) {
-    const uint32_t T = kth_largest_key(krow, Cp, k, lane);
-    int n_gt = 0;
-    for (int j = lane; j < Cp; j += 64) n_gt += __popcll(__ballot(krow[j] > T));
-    int need = k - n_gt;
     int base = 0;
-    for (int j = lane; j < Cp; j += 64) {
-        const uint32_t key = krow[j];
-        const unsigned long long eq = __ballot(key == T);
-        const bool take = (key > T) || (key == T && __popcll(eq & lanes_below(lane)) < need);
-        const unsigned long long sel = __ballot(take);
-        need -= min(need, (int)__popcll(eq));
+    topk_walk(krow, Cp, k, lane, [&](int j, uint32_t key, bool take, unsigned long long sel) {
         if (take) sortbuf[base + __popcll(sel & lanes_below(lane))] =
-            ((unsigned long long)key << 32) | (uint32_t)(~(uint32_t)j);
+            ((unsigned long long)key << 32) | (uint32_t)(~(uint32_t)(j * 64 + lane));
         base += __popcll(sel);
-    }
+    });
     for (int i = k + lane; i < npow2; i += 64) sortbuf[i] = 0ull;
     wave_lds_sync();
     for (int size = 2; size <= npow2; size <<= 1) {
@@ -218,22 +286,39 @@ __device__ __forceinline__ int select_pages(const uint32_t* cbits, int C, const 
     }
     const int limit = cap_pages ? min(P, page_len / 8) : P;   // cent_select.cpp:218,410-414
     int count = 0;
-    for (int base = 0; base < page_len; base += 64) {
-        const int i = base + lane;
-        const bool in = i < page_len;
-        int raw = in ? bt_row[i] : 0;
-        const int pg = min(max(raw, 0), kv_page_len - 1);   // tests/utils.py:62 clamps
-        const int cid = in ? ids_row[pg] : -1;
-        bool hit = in && cid >= 0 && cid < C && ((cbits[cid >> 5] >> (cid & 31)) & 1u);
-        if (sink_recent) hit = hit || (in && (raw == bt0 || raw == btm1 || raw == btm2));
-        const unsigned long long hb = __ballot(hit);
-        const int slot = count + __popcll(hb & lanes_below(lane));
-        if (hit && slot < P && pos_row) pos_row[slot] = i;
-        if (pbits) {
-            const unsigned long long ab = __ballot(hit && slot < limit);
-            if (lane == 0) pbits[base >> 6] = ab;
+    for (int base0 = 0; base0 < page_len; base0 += 256) {
+        // both dependent loads (block_table, then block_ids) of four 64-page slices are issued together:
+        // two round trips per 256 pages instead of eight
+        int raw[4], cid[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = base0 + u * 64 + lane;
+            raw[u] = (i < page_len) ? bt_row[i] : 0;
         }
-        count += __popcll(hb);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = base0 + u * 64 + lane;
+            const int pg = min(max(raw[u], 0), kv_page_len - 1);   // tests/utils.py:62 clamps
+            cid[u] = (i < page_len) ? ids_row[pg] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int base = base0 + u * 64;
+            if (base < page_len) {
+                const int i = base + lane;
+                const bool in = i < page_len;
+                bool hit = in && cid[u] >= 0 && cid[u] < C && ((cbits[cid[u] >> 5] >> (cid[u] & 31)) & 1u);
+                if (sink_recent) hit = hit || (in && (raw[u] == bt0 || raw[u] == btm1 || raw[u] == btm2));
+                const unsigned long long hb = __ballot(hit);
+                const int slot = count + __popcll(hb & lanes_below(lane));
+                if (hit && slot < P && pos_row) pos_row[slot] = i;
+                if (pbits) {
+                    const unsigned long long ab = __ballot(hit && slot < limit);
+                    if (lane == 0) pbits[base >> 6] = ab;
+                }
+                count += __popcll(hb);
+            }
+        }
     }
     if (pbits)
         for (int w = ((page_len + 63) >> 6) + lane; w < n_pwords; w += 64) pbits[w] = 0ull;
@@ -261,7 +346,7 @@ __global__ __launch_bounds__(kThreads) void cent_kernel(const CentParams p) {
     for (int g0 = 0; g0 < p.G; g0 += RG) {
         const int R = min(RG, p.G - g0);
         const long long row0 = (long long)b * p.Hq + (long long)n2 * p.G + g0;
-        score_rows(p.q, p.cent, p.qk_dtype, row0, n2, R, p.D, p.C, p.Cp, keys);
+        score_rows<4>(p.q, p.cent, p.qk_dtype, row0, n2, R, p.D, p.C, p.Cp, keys);
         __syncthreads();
         for (int r = wave; r < R; r += 4) {
             const long long row = row0 + r;
@@ -330,12 +415,30 @@ __global__ __launch_bounds__(kThreads) void select_position_kernel(const SelectP
 }
 
 // ------------------------------------------------------------------------------------------------
-// attention
+// attention: persistent, wave-specialised kernel
+//
+//   work item  = (batch, kv head, pass of up to NQ q heads)          [per-head lists: (batch, q head)]
+//   workgroup  = 5 waves: waves 0-3 stream K/V pages of the CURRENT item, wave 4 (the selector)
+//                prepares the NEXT item meanwhile: Q.Cent^T, top-k, page selection, the union page
+//                list and the pre-scaled q rows go into the other half of a double-buffered LDS area.
+//   One __syncthreads() per item hands the buffers over.  Selection work (latency bound, no HBM
+//   traffic) is therefore hidden behind the HBM-bound page stream instead of preceding it.
+//   Items are pulled from 8 counters (one per XCD class, item % 8) so that the kv heads an XCD works on
+//   keep their centroids in that XCD's L2; a workgroup whose class is exhausted steals from the others,
+//   so every item is processed whatever the placement.
 // ------------------------------------------------------------------------------------------------
 struct PageEntry {            // 16 bytes in LDS
     int phys;                 // physical block
     int valid;                // attended tokens of the page
     unsigned long long mask;  // bit g: head g of the pass attends this page
+};
+struct ItemHdr {              // 32 bytes in LDS
+    int item;                 // < 0: no more work
+    int nU;                   // page list length
+    int b, n2;
+    int row0;                 // first output row (b * Hq + head) of the pass
+    int R;                    // q heads in the pass
+    int pad[2];
 };
 
 template <typename KVT> struct KvTraits;
@@ -376,57 +479,136 @@ __device__ __forceinline__ void merge_state(float& m, float& l, float* o, int n,
     m = mt;
 }
 
+// Build-time tuning knobs (defaults are the shipped configuration).
+#ifndef SPFA_MINWAVES
+#define SPFA_MINWAVES 4      // launch-bounds waves per SIMD of the one-q-head kernels
+#endif
+#ifndef SPFA_LG1
+#define SPFA_LG1 2           // wave loads of K (and of V) per step, one-q-head kernels: short bursts keep the
+                             // CU's memory queue shallow, so the selector wave's dependent loads return quickly
+#endif
+#ifndef SPFA_KV_AUX
+#define SPFA_KV_AUX 2       // cache policy bits of the K/V buffer loads (2 = nt: read once, do not displace the
+                             // centroids and tables from L2)
+#endif
+#ifndef SPFA_WGS_PER_CU
+#define SPFA_WGS_PER_CU 2     // resident workgroups per CU of the persistent grid (upper bound)
+#endif
+#ifndef SPFA_BUFLOAD
+#define SPFA_BUFLOAD 1       // 1: buffer loads with scalar offsets, 0: global loads
+#endif
+// Diagnostic builds (-DSPFA_STAMPS) record s_memtime stamps of the item pipeline into AttnParams::debug;
+// the shipped kernel contains none of this.
+#ifdef SPFA_STAMPS
+#define SPFA_STAMP(slotidx)                                                                         \
+    do {                                                                                            \
+        if (p.debug && lane == 0)                                                                   \
+            p.debug[((size_t)blockIdx.x * 16 + stamp_item) * 16 + (slotidx)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define SPFA_STAMP(slotidx) do {} while (0)
+#endif
+constexpr int kStreamWaves = 4;
+constexpr int kAttnThreads = 64 * (kStreamWaves + 1);
+
+// Pull the next work item.  Class c holds items c, c+8, ...; start with this XCD's class.
+// The first item of every workgroup is static (item = blockIdx.x, which is the (blockIdx.x / 8)-th item of
+// class blockIdx.x % 8), so the counters only hand out the items behind those.
+__device__ __forceinline__ int fetch_item(unsigned* counters, int xcd, int total, int grid, int lane) {
+    int item = -1;
+    if (lane == 0) {
+        for (int t = 0; t < 8 && item < 0; ++t) {
+            const int c = (xcd + t) & 7;
+            const int n_c = (total - c + 7) >> 3;      // items of class c
+            const int first = (grid - c + 7) >> 3;     // of which statically assigned
+            if (n_c <= first) continue;
+            const unsigned i = atomicAdd(&counters[c], 1u) + (unsigned)first;
+            if (i < (unsigned)n_c) item = c + 8 * (int)i;
+        }
+    }
+    return __builtin_amdgcn_readfirstlane(item);
+}
+
 template <typename KVT, int NQ, int LPT>
-__global__ __launch_bounds__(kThreads) void attn_kernel(const AttnParams p) {
+__global__ __launch_bounds__(kAttnThreads, (NQ == 1 ? SPFA_MINWAVES : (NQ <= 4 ? 2 : 1))) void attn_kernel(const AttnParams p) {
     constexpr int EPL = KvTraits<KVT>::EPL;     // elements per 16-byte lane load
     constexpr int TPL = 64 / LPT;               // tokens per wave load
-    constexpr int LG = (NQ * EPL <= 16) ? 8 : ((NQ * EPL <= 32) ? 4 : 2);   // loads per step and cache
+    constexpr int LG = (NQ * EPL <= 16) ? SPFA_LG1 : ((NQ * EPL <= 32) ? 4 : 2);   // wave loads of K (and V) per step
+    constexpr int STEP = TPL * LG;
     constexpr bool QUANT = sizeof(KVT) == 1;
     constexpr float kNegBig = -1.0e30f;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = lane_id(), wave = wave_id();
+    const bool selector = wave == kStreamWaves;
     const int sub = lane % LPT;                 // 16-byte slice of the head row
     const int grp = lane / LPT;                 // token within a wave load
     const int D = p.D;
+    const bool per_head = (p.mode == 0 && p.pos_rows == p.Hq && p.G > 1);   // every q head has its own list
+    const int G_eff = per_head ? 1 : p.G;
+    const int n_pass = (G_eff + NQ - 1) / NQ;
+    const int heads_per_b = per_head ? p.Hq : p.Hkv;
+    const int total = p.B * heads_per_b * n_pass;
 
-    int b, n2, head0, G_eff;
-    if (p.mode == 0 && p.pos_rows == p.Hq && p.G > 1) {   // every q head has its own list
-        b = blockIdx.x / p.Hq;
-        head0 = blockIdx.x % p.Hq;
-        n2 = head0 / p.G;
-        G_eff = 1;
-    } else {
-        n2 = blockIdx.x % p.Hkv;
-        b = blockIdx.x / p.Hkv;
-        head0 = n2 * p.G;
-        G_eff = p.G;
-    }
-    PageEntry* list = (PageEntry*)smem;                          // aliases the score keys
-    uint32_t* keys = (uint32_t*)smem;
-    uint32_t* cbits_all = (uint32_t*)(smem + p.off_cbits);       // [4 waves][Cp/32]
-    unsigned long long* pbits_all = (unsigned long long*)(smem + p.off_pbits);   // [NQ][n_pwords]
-    int* misc = (int*)(smem + p.off_misc);                       // [0] = list length
+    uint32_t* keys = (uint32_t*)(smem + p.off_keys);                              // [NQ][Cp]   (selector)
+    uint32_t* cbits = (uint32_t*)(smem + p.off_cbits);                            // [Cp/32]    (selector)
+    unsigned long long* pbits_all = (unsigned long long*)(smem + p.off_pbits);    // [NQ][n_pwords] (selector)
+    PageEntry* lists = (PageEntry*)(smem + p.off_list);                           // [2][max_entries]
+    float* combs = (float*)(smem + p.off_comb);                                   // [2][4][NQ][D+2]
+    float* qsts = (float*)(smem + p.off_qst);                                     // [2][NQ][D]
+    ItemHdr* hdrs = (ItemHdr*)(smem + p.off_hdr);                                 // [2]
     const int n_pwords = (p.max_page + 63) >> 6;
-    const int32_t* bt_row = p.block_table + (long long)b * p.max_page;
-
-    int page_len = 0, seq = 0, len_max = 0;
-    if (p.mode == 1) {
-        seq = p.seq_len[b];
-        page_len = max(0, min((seq + p.block_size - 1) / p.block_size, p.max_page));
-    }
+    const int cstride = D + 2;
     const float qscale = p.scale * 1.4426950408889634f;   // scores in base-2 exponent units
+    // Workgroups are dealt round-robin over the 8 XCDs, so blockIdx % 8 labels the workgroups that share an
+    // XCD (and its L2).  Used for L2 affinity of the centroids only, never for correctness.
+    const int xcd = blockIdx.x & 7;
+#ifdef SPFA_STAMPS
+    int stamp_item = 0;
+#endif
 
-    for (int g0 = 0; g0 < G_eff; g0 += NQ) {
-        const int R = min(NQ, G_eff - g0);
-        const long long row0 = (long long)b * p.Hq + head0 + g0;
-        // ---------------- phase A: page list of this pass into LDS ----------------
+    // ---------------- selector: everything that precedes the page stream of one item ----------------
+    struct ItemCtx { int b, n2, head0, R; long long row0; };
+    auto decode = [&](int item) {
+        // item -> (batch, head, pass); item % 8 picks the XCD class, so keep the kv head in the low part
+        ItemCtx c;
+        const int hh = item % heads_per_b;
+        const int rest = item / heads_per_b;
+        const int pass = rest % n_pass;
+        c.b = rest / n_pass;
+        c.n2 = per_head ? hh / p.G : hh;
+        c.head0 = per_head ? hh : c.n2 * p.G + pass * NQ;
+        c.R = min(NQ, G_eff - pass * NQ);
+        c.row0 = (long long)c.b * p.Hq + c.head0;
+        return c;
+    };
+    // item < 0: fetch the next one; scored: the keys of this item are already in LDS
+    auto build = [&](int slot, int item, bool scored) {
+        ItemHdr* hdr = hdrs + slot;
+        PageEntry* list = lists + (size_t)slot * p.max_entries;
+        float* qst = qsts + (size_t)slot * NQ * D;
+        SPFA_STAMP(0);
+        if (item < 0) item = fetch_item(p.counters, xcd, total, (int)gridDim.x, lane);
+        SPFA_STAMP(1);
+        if (item < 0) {
+            if (lane == 0) hdr->item = -1;
+            return;
+        }
+        const ItemCtx ctx = decode(item);
+        const int b = ctx.b, n2 = ctx.n2, head0 = ctx.head0, R = ctx.R;
+        const long long row0 = ctx.row0;
+        const int32_t* bt_row = p.block_table + (long long)b * p.max_page;
+        int nU = 0;
         if (p.mode == 1) {
-            score_rows(p.q, p.cent, p.q_dtype, row0, n2, R, D, p.C, p.Cp, keys);
-            __syncthreads();
-            for (int r = wave; r < R; r += 4) {
-                uint32_t* cbits = cbits_all + (size_t)wave * (p.Cp >> 5);
+            const int seq = p.seq_len[b];
+            const int page_len = max(0, min((seq + p.block_size - 1) / p.block_size, p.max_page));
+            if (!scored) score_rows<1>(p.q, p.cent, p.q_dtype, row0, n2, R, D, p.C, p.Cp, keys);
+            wave_lds_sync();
+            SPFA_STAMP(2);
+            int len_max = 0;
+            for (int r = 0; r < R; ++r) {
                 topk_bitmap(keys + r * p.Cp, p.Cp, p.k, cbits, lane);
                 wave_lds_sync();
+                SPFA_STAMP(3);
                 const long long row = row0 + r;
                 const int len = select_pages(cbits, p.C, bt_row, p.block_ids + (long long)n2 * p.kv_page_len,
                                              p.kv_page_len, page_len, p.P, p.sink_recent, p.cap_pages,
@@ -434,66 +616,87 @@ __global__ __launch_bounds__(kThreads) void attn_kernel(const AttnParams p) {
                                              pbits_all + (size_t)r * n_pwords, n_pwords, lane);
                 if (p.page_position_length && lane < kLenPad) p.page_position_length[row * kLenPad + lane] = len;
                 len_max = max(len_max, len);
+                wave_lds_sync();
             }
-            __syncthreads();   // keys are dead from here on: the list may overwrite them
-            if (wave == 0) {
-                int nU = 0;
-                for (int w = 0; w < ((page_len + 63) >> 6); ++w) {
-                    unsigned long long u = 0, mine = 0;
-                    for (int r = 0; r < R; ++r) {
-                        const unsigned long long x = pbits_all[(size_t)r * n_pwords + w];
-                        u |= x;
-                        mine |= ((x >> lane) & 1ull) << r;
-                    }
-                    if ((u >> lane) & 1ull) {
-                        const int i = w * 64 + lane;
-                        const int e = nU + __popcll(u & lanes_below(lane));
-                        if (e < p.max_entries) {
-                            PageEntry pe;
-                            pe.phys = min(max(bt_row[i], 0), p.n_blocks - 1);
-                            pe.valid = min(p.block_size, seq - i * p.block_size);
-                            pe.mask = mine;
-                            list[e] = pe;
-                        }
-                    }
-                    nU += __popcll(u);
+            if (p.max_page_position_length && lane < kLenPad && len_max > 0)   // cent_select.cpp:124-152
+                atomicMax(p.max_page_position_length + (long long)b * kLenPad + lane,
+                          (unsigned long long)len_max * (unsigned long long)p.block_size);
+            SPFA_STAMP(4);
+            // union of the pass's page lists, ascending, with a per-page head mask
+            for (int w = 0; w < ((page_len + 63) >> 6); ++w) {
+                unsigned long long u = 0, mine = 0;
+                for (int r = 0; r < R; ++r) {
+                    const unsigned long long x = pbits_all[(size_t)r * n_pwords + w];
+                    u |= x;
+                    mine |= ((x >> lane) & 1ull) << r;
                 }
-                if (lane == 0) misc[0] = min(nU, p.max_entries);
+                if ((u >> lane) & 1ull) {
+                    const int i = w * 64 + lane;
+                    const int e = nU + __popcll(u & lanes_below(lane));
+                    if (e < p.max_entries) {
+                        PageEntry pe;
+                        pe.phys = min(max(bt_row[i], 0), p.n_blocks - 1);
+                        pe.valid = min(p.block_size, seq - i * p.block_size);
+                        pe.mask = mine;
+                        list[e] = pe;
+                    }
+                }
+                nU += __popcll(u);
             }
         } else {
             // list = leading non-sentinel slots of the row, bounded by actual_seq_lengths
             // (…Us2.h:256-294; the kernel stops at the first 0x7fffffff, :308-311)
-            if (wave == 0) {
-                const int prow = (p.pos_rows == p.Hq) ? (head0 + g0) : n2;
-                const int32_t* pos = p.block_position + ((long long)b * p.pos_rows + prow) * p.P;
-                long long n_tok = p.act_seq ? p.act_seq[b] : (p.act_seq_uniform >= 0 ? p.act_seq_uniform : (long long)p.P * p.block_size);
-                n_tok = max(0ll, min(n_tok, (long long)p.P * p.block_size));
-                const int n_slots = (int)((n_tok + p.block_size - 1) / p.block_size);
-                int nU = 0;
-                bool open = true;
-                for (int base = 0; base < n_slots && open; base += 64) {
-                    const int j = base + lane;
-                    const int pg = (j < n_slots) ? pos[j] : kSentinel;
-                    const bool stop = (pg == kSentinel) || pg < 0 || pg >= p.max_page;
-                    const unsigned long long sb = __ballot(stop);
-                    const int first = sb ? (__ffsll((long long)sb) - 1) : 64;
-                    if (lane < first && nU + lane < p.max_entries) {
-                        PageEntry pe;
-                        pe.phys = min(max(bt_row[pg], 0), p.n_blocks - 1);
-                        pe.valid = (int)min((long long)p.block_size, n_tok - (long long)j * p.block_size);
-                        pe.mask = ~0ull;
-                        list[nU + lane] = pe;
-                    }
-                    nU += first;
-                    open = (first == 64);
+            const int prow = (p.pos_rows == p.Hq) ? head0 : n2;
+            const int32_t* pos = p.block_position + ((long long)b * p.pos_rows + prow) * p.P;
+            long long n_tok = p.act_seq ? p.act_seq[b]
+                                        : (p.act_seq_uniform >= 0 ? p.act_seq_uniform : (long long)p.P * p.block_size);
+            n_tok = max(0ll, min(n_tok, (long long)p.P * p.block_size));
+            const int n_slots = (int)((n_tok + p.block_size - 1) / p.block_size);
+            bool open = true;
+            for (int base = 0; base < n_slots && open; base += 64) {
+                const int j = base + lane;
+                const int pg = (j < n_slots) ? pos[j] : kSentinel;
+                const bool stop = (pg == kSentinel) || pg < 0 || pg >= p.max_page;
+                const unsigned long long sb = __ballot(stop);
+                const int first = sb ? (__ffsll((long long)sb) - 1) : 64;
+                if (lane < first && nU + lane < p.max_entries) {
+                    PageEntry pe;
+                    pe.phys = min(max(bt_row[pg], 0), p.n_blocks - 1);
+                    pe.valid = (int)min((long long)p.block_size, n_tok - (long long)j * p.block_size);
+                    pe.mask = (1ull << R) - 1ull;
+                    list[nU + lane] = pe;
                 }
-                if (lane == 0) misc[0] = min(nU, p.max_entries);
+                nU += first;
+                open = (first == 64);
             }
         }
-        __syncthreads();
-        const int nU = misc[0];
+        SPFA_STAMP(5);
+        // pre-scaled q rows (int8 KV: times the per-channel key scale, …Us2.h:2647)
+        for (int t = lane; t < NQ * D; t += 64) {
+            const int g = t / D, d = t - g * D;
+            float v = 0.f;
+            if (g < R) {
+                v = load_qk_elem(p.q, p.q_dtype, (row0 + g) * D + d) * qscale;
+                if (QUANT) v *= load_qk_elem(p.antiq_scale, p.q_dtype, (long long)n2 * D + d);
+            }
+            qst[t] = v;
+        }
+        SPFA_STAMP(6);
+        if (lane == 0) {
+            hdr->item = item;
+            hdr->nU = min(nU, p.max_entries);
+            hdr->b = b;
+            hdr->n2 = n2;
+            hdr->row0 = (int)row0;
+            hdr->R = R;
+        }
+    };
 
-        // ---------------- phase B: stream the pages ----------------
+    // ---------------- streamers: K/V pages of one item -> partial softmax states in LDS ----------------
+    auto stream = [&](int slot, int nU, int n2) {
+        const PageEntry* list = lists + (size_t)slot * p.max_entries;
+        const float* qst = qsts + (size_t)slot * NQ * D;
+        float* comb = combs + (size_t)slot * kStreamWaves * NQ * cstride;
         float qf[NQ][EPL];
         float qbias[NQ];   // int8: 128 * sum of this lane's q' (u = x + 128)
 #pragma unroll
@@ -501,13 +704,8 @@ __global__ __launch_bounds__(kThreads) void attn_kernel(const AttnParams p) {
             qbias[g] = 0.f;
 #pragma unroll
             for (int e = 0; e < EPL; ++e) {
-                float v = 0.f;
-                if (g < R) {
-                    v = load_qk_elem(p.q, p.q_dtype, (row0 + g) * D + sub * EPL + e) * qscale;
-                    if (QUANT) v *= load_qk_elem(p.antiq_scale, p.q_dtype, (long long)n2 * D + sub * EPL + e);
-                }
-                qf[g][e] = v;
-                qbias[g] += 128.f * v;
+                qf[g][e] = qst[g * D + sub * EPL + e];
+                qbias[g] += 128.f * qf[g][e];
             }
         }
         float o[NQ][EPL], m[NQ], l[NQ];
@@ -518,25 +716,46 @@ __global__ __launch_bounds__(kThreads) void attn_kernel(const AttnParams p) {
 #pragma unroll
             for (int e = 0; e < EPL; ++e) o[g][e] = 0.f;
         }
-        const unsigned lane_off = (unsigned)(sub * 16);
-        for (int n = wave; n < nU; n += 4) {
+        // Addressing: one buffer descriptor per page and head (uniform, SGPRs) + a per-lane byte offset
+        // that never changes (token group * token stride + 16-byte slice) + a scalar offset per wave
+        // load.  The descriptor's range ends at the page's last row of this head, so token slots past the
+        // block size read zeros instead of faulting.
+        const int lane_off = grp * (int)p.tok_stride + sub * 16;
+        const int page_range = (p.block_size - 1) * (int)p.tok_stride + D * (int)sizeof(KVT);
+        for (int n = wave; n < nU; n += kStreamWaves) {
             const int phys = __builtin_amdgcn_readfirstlane(list[n].phys);
             const int valid = __builtin_amdgcn_readfirstlane(list[n].valid);
-            const unsigned mlo = __builtin_amdgcn_readfirstlane((unsigned)list[n].mask);
-            const char* kp = (const char*)p.kcache + (long long)phys * p.blk_stride + (long long)n2 * p.head_stride;
-            const char* vp = (const char*)p.vcache + (long long)phys * p.blk_stride + (long long)n2 * p.head_stride;
-            for (int t0 = 0; t0 < valid; t0 += TPL * LG) {
+            const unsigned mask = __builtin_amdgcn_readfirstlane((unsigned)list[n].mask);
+            const long long off = (long long)phys * p.blk_stride + (long long)n2 * p.head_stride;
+            const __amdgpu_buffer_rsrc_t rk =
+                __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.kcache + off), 0, page_range, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rv =
+                __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.vcache + off), 0, page_range, 0x00020000);
+            for (int t0 = 0; t0 < valid; t0 += STEP) {
                 uint4 kreg[LG], vreg[LG];
+#if SPFA_BUFLOAD
+#pragma unroll
+                for (int i = 0; i < LG; ++i)
+                    kreg[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                            rk, lane_off, (t0 + i * TPL) * (int)p.tok_stride, SPFA_KV_AUX));
+#pragma unroll
+                for (int i = 0; i < LG; ++i)
+                    vreg[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                            rv, lane_off, (t0 + i * TPL) * (int)p.tok_stride, SPFA_KV_AUX));
+#else
+                const char* kp = (const char*)p.kcache + off;
+                const char* vp = (const char*)p.vcache + off;
 #pragma unroll
                 for (int i = 0; i < LG; ++i) {
                     const int tok = min(t0 + i * TPL + grp, p.block_size - 1);
-                    kreg[i] = *(const uint4*)(kp + (unsigned)(tok * (int)p.tok_stride) + lane_off);
+                    kreg[i] = *(const uint4*)(kp + (unsigned)(tok * (int)p.tok_stride) + (unsigned)(sub * 16));
                 }
 #pragma unroll
                 for (int i = 0; i < LG; ++i) {
                     const int tok = min(t0 + i * TPL + grp, p.block_size - 1);
-                    vreg[i] = *(const uint4*)(vp + (unsigned)(tok * (int)p.tok_stride) + lane_off);
+                    vreg[i] = *(const uint4*)(vp + (unsigned)(tok * (int)p.tok_stride) + (unsigned)(sub * 16));
                 }
+#endif
                 float s[NQ][LG];
 #pragma unroll
                 for (int i = 0; i < LG; ++i) {
@@ -554,7 +773,7 @@ __global__ __launch_bounds__(kThreads) void attn_kernel(const AttnParams p) {
                 }
 #pragma unroll
                 for (int g = 0; g < NQ; ++g) {
-                    if (!((mlo >> g) & 1u)) {   // wave-uniform: this head does not attend the page
+                    if (!((mask >> g) & 1u)) {   // wave-uniform: this head does not attend the page
 #pragma unroll
                         for (int i = 0; i < LG; ++i) s[g][i] = 0.f;
                         continue;
@@ -578,7 +797,7 @@ __global__ __launch_bounds__(kThreads) void attn_kernel(const AttnParams p) {
                     unpack16<KVT>(vreg[i], vf);
 #pragma unroll
                     for (int g = 0; g < NQ; ++g) {
-                        if ((mlo >> g) & 1u) {
+                        if ((mask >> g) & 1u) {
 #pragma unroll
                             for (int e = 0; e < EPL; ++e) o[g][e] = fmaf(s[g][i], vf[e], o[g][e]);
                         }
@@ -586,7 +805,7 @@ __global__ __launch_bounds__(kThreads) void attn_kernel(const AttnParams p) {
                 }
             }
         }
-        // ---------------- merge the 64/LPT token groups of the wave, then the 4 waves ----------------
+        // merge the 64/LPT token groups of the wave; the 4 waves are merged after the hand-over barrier
 #pragma unroll
         for (int g = 0; g < NQ; ++g) {
             if (QUANT) {
@@ -601,12 +820,6 @@ __global__ __launch_bounds__(kThreads) void attn_kernel(const AttnParams p) {
                 for (int e = 0; e < EPL; ++e) o2[e] = __shfl_xor(o[g][e], step);
                 merge_state(m[g], l[g], o[g], EPL, m2, l2, o2);
             }
-        }
-        __syncthreads();   // every wave is done with the page list: reuse its LDS for the merge
-        float* comb = (float*)smem;   // [4 waves][NQ][D + 2]
-        const int cstride = D + 2;
-#pragma unroll
-        for (int g = 0; g < NQ; ++g) {
             float* dst = comb + ((size_t)wave * NQ + g) * cstride;
             if (grp == 0) {
 #pragma unroll
@@ -614,13 +827,17 @@ __global__ __launch_bounds__(kThreads) void attn_kernel(const AttnParams p) {
                 if (sub == 0) { dst[D] = m[g]; dst[D + 1] = l[g]; }
             }
         }
-        __syncthreads();
-        for (int t = threadIdx.x; t < R * D; t += kThreads) {
-            const int g = t / D, d = t % D;
+    };
+
+    // ---------------- merge the 4 streamer states of a finished item and store its output rows ----------------
+    auto finalize = [&](int slot, int row0, int R, int n2) {
+        const float* comb = combs + (size_t)slot * kStreamWaves * NQ * cstride;
+        for (int t = threadIdx.x; t < R * D; t += kStreamWaves * 64) {
+            const int g = t / D, d = t - g * D;
             float mt = kNegBig;
-            for (int w = 0; w < 4; ++w) mt = fmaxf(mt, comb[((size_t)w * NQ + g) * cstride + D]);
+            for (int w = 0; w < kStreamWaves; ++w) mt = fmaxf(mt, comb[((size_t)w * NQ + g) * cstride + D]);
             float acc = 0.f, lt = 0.f;
-            for (int w = 0; w < 4; ++w) {
+            for (int w = 0; w < kStreamWaves; ++w) {
                 const float* src = comb + ((size_t)w * NQ + g) * cstride;
                 const float c = fast_exp2(src[D] - mt);
                 acc += src[d] * c;
@@ -632,48 +849,115 @@ __global__ __launch_bounds__(kThreads) void attn_kernel(const AttnParams p) {
                 if (p.antiq_offset) r += load_qk_elem(p.antiq_offset, p.q_dtype, pi);
                 r *= load_qk_elem(p.antiq_scale, p.q_dtype, pi);
             }
-            const long long oi = (row0 + g) * D + d;
+            const long long oi = ((long long)row0 + g) * D + d;
             if (p.out_dtype == kF32) ((float*)p.out)[oi] = r;
             else if (p.out_dtype == kBF16) ((__bf16*)p.out)[oi] = (__bf16)r;   // round to nearest even (…Us2.h:3476-3477)
             else ((_Float16*)p.out)[oi] = (_Float16)r;
         }
-        __syncthreads();
+    };
+
+    // ---------------- item pipeline ----------------
+    // First item: static (no counter round trip) and scored by all five waves together, because nothing can
+    // be streamed before the first page list exists.
+    int slot = 0;
+    {
+        const int item0 = (int)blockIdx.x;   // grid <= total
+        if (p.mode == 1) {
+            const ItemCtx c0 = decode(item0);
+            score_rows<kStreamWaves + 1>(p.q, p.cent, p.q_dtype, c0.row0, c0.n2, c0.R, D, p.C, p.Cp, keys);
+            __syncthreads();
+        }
+        if (selector) build(0, item0, true);
     }
-    if (p.mode == 1 && p.max_page_position_length && lane < kLenPad && len_max > 0)
-        atomicMax(p.max_page_position_length + (long long)b * kLenPad + lane,
-                  (unsigned long long)len_max * (unsigned long long)p.block_size);
+    __syncthreads();
+#ifdef SPFA_STAMPS
+    stamp_item = 1;
+#endif
+    int prev_row0 = 0, prev_R = 0, prev_n2 = 0;
+    bool have_prev = false;
+    while (true) {
+        const int item = __builtin_amdgcn_readfirstlane(hdrs[slot].item);
+        const int nU = __builtin_amdgcn_readfirstlane(hdrs[slot].nU);
+        const int n2 = __builtin_amdgcn_readfirstlane(hdrs[slot].n2);
+        const int row0 = __builtin_amdgcn_readfirstlane(hdrs[slot].row0);
+        const int R = __builtin_amdgcn_readfirstlane(hdrs[slot].R);
+        if (have_prev && !selector) finalize(slot ^ 1, prev_row0, prev_R, prev_n2);
+        if (item < 0) break;
+        if (selector) build(slot ^ 1, -1, false);
+        else {
+            if (wave == 0) SPFA_STAMP(8);
+            stream(slot, nU, n2);
+            if (wave == 0) SPFA_STAMP(9);
+        }
+        __syncthreads();
+        if (wave == 0) SPFA_STAMP(10);
+#ifdef SPFA_STAMPS
+        stamp_item = min(stamp_item + 1, 15);
+#endif
+        prev_row0 = row0; prev_R = R; prev_n2 = n2; have_prev = true;
+        slot ^= 1;
+    }
+}
+
+template <typename KVT, int NQ, int LPT>
+hipError_t launch_attn_one(const AttnParams& p, hipStream_t s) {
+    auto kern = attn_kernel<KVT, NQ, LPT>;
+    static int blocks_per_cu = 0, n_cu = 0;   // per (kernel, process): residency of the persistent grid
+    if (blocks_per_cu == 0 || p.lds_bytes > 48 * 1024) {
+        if (p.lds_bytes > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)p.lds_bytes);
+            if (e != hipSuccess) return e;
+        }
+    }
+    int dev = 0, occ = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (n_cu == 0) {
+        e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess) return e;
+    }
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, kAttnThreads, p.lds_bytes);
+    if (e != hipSuccess) return e;
+    blocks_per_cu = occ < 1 ? 1 : occ;
+    // 8 streamer waves per CU already saturate HBM; a third workgroup only deepens the memory queues
+    if (blocks_per_cu > SPFA_WGS_PER_CU) blocks_per_cu = SPFA_WGS_PER_CU;
+    const bool per_head = (p.mode == 0 && p.pos_rows == p.Hq && p.G > 1);
+    const int g_eff = per_head ? 1 : p.G;
+    const long long total = (long long)p.B * (per_head ? p.Hq : p.Hkv) * ((g_eff + NQ - 1) / NQ);
+    if (total == 0) return hipSuccess;
+    const long long cap = (long long)n_cu * blocks_per_cu;
+    const dim3 grid((unsigned)(total < cap ? total : cap));
+    static bool said = false;
+    if (!said && getenv("SPFA_DEBUG")) {
+        said = true;
+        fprintf(stderr, "[spfa] attn grid=%u blocks/CU=%d CUs=%d lds=%zu items=%lld\n", grid.x, blocks_per_cu, n_cu, p.lds_bytes, total);
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(kAttnThreads), p.lds_bytes, s, p);
+    return hipGetLastError();
 }
 
 template <typename KVT, int NQ>
-hipError_t launch_attn_lpt(const AttnParams& p, int lpt, dim3 grid, hipStream_t s) {
-#define SPFA_LAUNCH(L)                                                                          \
-    case L: {                                                                                   \
-        auto kern = attn_kernel<KVT, NQ, L>;                                                    \
-        if (p.lds_bytes > 48 * 1024) {                                                          \
-            hipError_t e = hipFuncSetAttribute((const void*)kern,                               \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize,      \
-                                               (int)p.lds_bytes);                               \
-            if (e != hipSuccess) return e;                                                      \
-        }                                                                                       \
-        hipLaunchKernelGGL(kern, grid, dim3(kThreads), p.lds_bytes, s, p);                      \
-        return hipGetLastError();                                                               \
-    }
+hipError_t launch_attn_lpt(const AttnParams& p, int lpt, hipStream_t s) {
     switch (lpt) {
-        SPFA_LAUNCH(4)
-        SPFA_LAUNCH(8)
-        SPFA_LAUNCH(16)
-        SPFA_LAUNCH(32)
+#ifndef SPFA_EXPLORE
+        case 4: return launch_attn_one<KVT, NQ, 4>(p, s);
+        case 8: return launch_attn_one<KVT, NQ, 8>(p, s);
+        case 32: return launch_attn_one<KVT, NQ, 32>(p, s);
+#endif
+        case 16: return launch_attn_one<KVT, NQ, 16>(p, s);
     }
-#undef SPFA_LAUNCH
     return hipErrorInvalidValue;
 }
 
 template <typename KVT>
-hipError_t launch_attn_nq(const AttnParams& p, int nq, int lpt, dim3 grid, hipStream_t s) {
+hipError_t launch_attn_nq(const AttnParams& p, int nq, int lpt, hipStream_t s) {
     switch (nq) {
-        case 1: return launch_attn_lpt<KVT, 1>(p, lpt, grid, s);
-        case 4: return launch_attn_lpt<KVT, 4>(p, lpt, grid, s);
-        case 8: return launch_attn_lpt<KVT, 8>(p, lpt, grid, s);
+        case 1: return launch_attn_lpt<KVT, 1>(p, lpt, s);
+#ifndef SPFA_EXPLORE
+        case 4: return launch_attn_lpt<KVT, 4>(p, lpt, s);
+        case 8: return launch_attn_lpt<KVT, 8>(p, lpt, s);
+#endif
     }
     return hipErrorInvalidValue;
 }
@@ -690,12 +974,12 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
     const int nq = per_head ? 1 : p.rows_per_pass;
     const int esize = (p.kv_dtype == kI8) ? 1 : 2;
     const int lpt = p.D * esize / 16;
-    const dim3 grid((unsigned)((long long)p.B * (per_head ? p.Hq : p.Hkv)));
-    if (grid.x == 0) return hipSuccess;
     switch (p.kv_dtype) {
-        case kF16: return launch_attn_nq<_Float16>(p, nq, lpt, grid, s);
-        case kBF16: return launch_attn_nq<__bf16>(p, nq, lpt, grid, s);
-        case kI8: return launch_attn_nq<int8_t>(p, nq, lpt, grid, s);
+        case kF16: return launch_attn_nq<_Float16>(p, nq, lpt, s);
+#ifndef SPFA_EXPLORE
+        case kBF16: return launch_attn_nq<__bf16>(p, nq, lpt, s);
+        case kI8: return launch_attn_nq<int8_t>(p, nq, lpt, s);
+#endif
     }
     return hipErrorInvalidValue;
 }

@@ -81,8 +81,10 @@ struct AttnParams {
     int P;                         // slots per row (both modes)
     int rows_per_pass;             // q heads of a group handled per pass
     int max_entries;               // capacity of the per-workgroup page list
+    unsigned* counters;            // 8 work counters (workspace), zeroed before every launch
+    unsigned long long* debug;     // diagnostic builds only: [grid][16 items][16 stamps], else null
     // LDS carve (bytes from the dynamic base)
-    int off_cbits, off_pbits, off_misc;
+    int off_keys, off_cbits, off_pbits, off_list, off_comb, off_qst, off_hdr;
     size_t lds_bytes;
 };
 

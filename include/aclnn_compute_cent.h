@@ -8,7 +8,7 @@
  * are stale generations of the same op and are not provided.
  *
  * query [B,Hq,D] f16|bf16, l1Cent [Hkv,C,D] same dtype, indicesOut [B,Hq,k] int32.
- * D % 32 == 0, D <= 256, k <= min(C, 1024).
+ * D in {32, 64, 128, 256}, k <= min(C, 1024).
  */
 #ifndef SPFA_ACLNN_COMPUTE_CENT_H_
 #define SPFA_ACLNN_COMPUTE_CENT_H_

@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-phase cycle shares of the item pipeline (needs a -DSPFA_STAMPS library build)."""
+import ctypes
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "cann-ops-adv-vllm_amd"))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+import custom_ops  # noqa: E402
+from custom_ops import _abi  # noqa: E402
+
+a = bench.parse()
+dev = torch.device("cuda", 0)
+wl = bench.build_workload(a, dev, a.batch, a.seed, custom_ops)
+B, Hq, Hkv, D, bs = a.batch, a.heads, a.kv_heads, a.head_dim, a.block_size
+pos = torch.empty((B, Hq, 256), dtype=torch.int32, device=dev)
+plen = torch.empty((B, Hq, 8), dtype=torch.int32, device=dev)
+pmax = torch.empty((B, 8), dtype=torch.int64, device=dev)
+dbg = torch.zeros((1024, 16, 16), dtype=torch.int64, device=dev)
+_abi.lib.spfaSetDebugBuffer.argtypes = [ctypes.c_void_p]
+_abi.lib.spfaSetDebugBuffer(dbg.data_ptr())
+plan = custom_ops.PreparedFusion(wl["q"], wl["key"], wl["val"], wl["table"], wl["l1"], wl["block_ids"], wl["seq"],
+                                 pos, plen, pmax, Hq, D ** -0.5, Hkv, bs, k=a.topk)
+import numpy as np
+import time
+
+
+def report(tag, fn):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    dbg.zero_()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    fn()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3
+    d = dbg.cpu().numpy().astype("int64")
+    span = d.max() - d[d > 0].min()
+    print(f"--- {tag}: {us:.1f} us, stamp span {span} ticks ({span / us:.0f} ticks/us)")
+    return d
+
+
+e = torch.empty(0, dtype=wl["q"].dtype, device=dev)
+ei = torch.empty(0, dtype=torch.int64, device=dev)
+plan.run()
+torch.cuda.synchronize()
+act = pmax[:, 0].contiguous()
+d_attn = report("attention only", lambda: custom_ops.sparse_paged_attention(
+    wl["q"], wl["key"], wl["val"], e, e, act, e, e, e, e, e, e, e, wl["table"], ei, pos, Hq, D ** -0.5, "BNSD", Hkv, bs, 1))
+for it in range(5):
+    row = d_attn[:, it, :]
+    ms = (row[:, 9] > 0) & (row[:, 8] > 0)
+    if ms.any():
+        print(f"item#{it}: n={int(ms.sum())} stream={np.median(row[ms, 9] - row[ms, 8]):.0f} "
+              f"wait_after_stream={np.median(row[ms, 10] - row[ms, 9]):.0f} first_start={np.median(row[ms, 8]) - d_attn[d_attn > 0].min():.0f}")
+d = report("fused", plan.run)
+names = {(0, 1): "fetch", (1, 2): "score", (2, 3): "topk", (3, 4): "select", (4, 5): "union", (5, 6): "qstage"}
+for it in range(5):
+    row = d[:, it, :]
+    ok = row[:, 0] > 0
+    if not ok.any():
+        continue
+    parts = []
+    for (i, j), n in names.items():
+        m = ok & (row[:, j] > 0) & (row[:, i] > 0)
+        if m.any():
+            parts.append(f"{n}={np.median(row[m, j] - row[m, i]):.0f}")
+    ms = ok & (row[:, 9] > 0) & (row[:, 8] > 0)
+    if ms.any():
+        parts.append(f"stream={np.median(row[ms, 9] - row[ms, 8]):.0f} wait_after_stream={np.median(row[ms, 10] - row[ms, 9]):.0f} start={np.median(row[ms, 8]) - d[d > 0].min():.0f}")
+    print(f"item#{it}: n={int(ok.sum())} " + " ".join(parts))
