@@ -544,7 +544,8 @@ static aclnnStatus plan_lds(spfa::AttnParams& p) {
         off += align16(nq * p.Cp * 4);                                     // score keys (selector wave)
     }
     p.off_cbits = (int)off;
-    if (p.mode == 1) off += align16((size_t)(p.Cp / 32) * 4);              // top-k cluster bitmap
+    if (p.mode == 1)   // top-k cluster bitmaps (one per wave that selects a row of the first item) + 8 row lengths
+        off += align16((nq < 5 ? nq : 5) * (size_t)(p.Cp / 32) * 4) + 32;
     p.off_pbits = (int)off;
     if (p.mode == 1) off += align16(nq * ((p.max_page + 63) / 64) * 8);    // per-head page bitmaps
     p.off_list = (int)off;

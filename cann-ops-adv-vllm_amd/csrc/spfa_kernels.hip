@@ -166,6 +166,16 @@ __device__ __forceinline__ int wave_sum(int v) {
            __builtin_amdgcn_readlane(v, 48);
 }
 
+// Maximum of v over the 64 lanes (result uniform).
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    v = max(v, (uint32_t)dpp_i<0x128>((int)v));
+    v = max(v, (uint32_t)dpp_i<0x124>((int)v));
+    v = max(v, (uint32_t)dpp_i<0x4E>((int)v));
+    v = max(v, (uint32_t)dpp_i<0xB1>((int)v));
+    return max(max((uint32_t)__builtin_amdgcn_readlane((int)v, 0), (uint32_t)__builtin_amdgcn_readlane((int)v, 16)),
+               max((uint32_t)__builtin_amdgcn_readlane((int)v, 32), (uint32_t)__builtin_amdgcn_readlane((int)v, 48)));
+}
+
 // k-th largest key by a 32-step bitwise bisection: T grows bit by bit while at least k keys are >= T.
 // Every lane counts its own keys (compare + add-with-carry, no scalar round trip) and the 64 counts are
 // summed once per step.  KeyAt(j) returns this lane's j-th key, j in [0, nj).
@@ -183,9 +193,10 @@ __device__ __forceinline__ uint32_t bisect_kth(KeyAt key_at, int nj, int k) {
 
 // Walk the top-k of one row (Cp % 64 == 0, executed by one full wave): emit(j, key, take, sel) is called for
 // every 64-key slice j with this lane's key, whether it belongs to the top-k and the slice's ballot.
-// Keys equal to the k-th largest are taken in ascending cluster-id order.
+// Keys equal to the k-th largest are taken in ascending cluster-id order.  The row in LDS is used as scratch
+// and does not survive the call.
 template <typename Emit>
-__device__ __forceinline__ void topk_walk(const uint32_t* krow, int Cp, int k, int lane, Emit emit) {
+__device__ __forceinline__ void topk_walk(uint32_t* krow, int Cp, int k, int lane, Emit emit) {
     const int nj = Cp >> 6;
     auto finish = [&](auto key_at) {
         const uint32_t T = bisect_kth(key_at, nj, k);
@@ -201,18 +212,62 @@ __device__ __forceinline__ void topk_walk(const uint32_t* krow, int Cp, int k, i
             emit(j, key, take, sel);
         }
     };
-    if (nj <= 32) {   // C <= 2048: the row lives in registers for all 32 bisection steps
+    if (nj <= 32) {   // C <= 2048: the row lives in registers
         uint32_t kr[32];
+        uint32_t lmax = 0;
 #pragma unroll
-        for (int j = 0; j < 32; ++j) kr[j] = (j < nj) ? krow[j * 64 + lane] : 0u;
-        uint32_t T = 0;
-        for (int bit = 31; bit >= 0; --bit) {
-            const uint32_t cand = T | (1u << bit);
+        for (int j = 0; j < 32; ++j) {
+            kr[j] = (j < nj) ? krow[j * 64 + lane] : 0u;
+            lmax = max(lmax, kr[j]);
+        }
+        auto count_ge = [&](uint32_t x) {
             int c = 0;
 #pragma unroll
-            for (int j = 0; j < 32; ++j) c += (kr[j] >= cand) ? 1 : 0;   // padding keys are 0 < cand
-            if (wave_sum(c) >= k) T = cand;
+            for (int j = 0; j < 32; ++j) c += (kr[j] >= x) ? 1 : 0;   // padding keys are 0
+            return wave_sum(c);
+        };
+        // Integer bisection of the k-th largest key T between two bounds with known counts:
+        //   count(keys >= lo) = cnt_lo >= k   and   count(keys > hi) = cnt_hi < k.
+        // A full step costs a compare per key.  Two things keep the number of full steps small: the k-th largest of
+        // the 64 per-lane maxima (a subset of the keys, so never above T) starts lo close to T, and as soon as
+        // [lo, hi] holds at most 64 keys they are compacted to one per lane and the rest costs a ballot per step.
+        uint32_t hi = wave_max_u32(lmax), lo = 0;
+        int cnt_lo = nj * 64, cnt_hi = 0;
+        if (k <= 64 && nj > 1) {
+            uint32_t a = 0, b = hi;
+            for (int s = 0; s < 20 && a < b; ++s) {
+                const uint32_t mid = a + ((b - a) >> 1) + 1;
+                if ((int)__popcll(__ballot(lmax >= mid)) >= k) a = mid; else b = mid - 1;
+            }
+            if (a) { lo = a; cnt_lo = count_ge(lo); }
         }
+        while (lo < hi && cnt_lo - cnt_hi > 64) {
+            const uint32_t mid = lo + ((hi - lo) >> 1) + 1;
+            const int c = count_ge(mid);
+            if (c >= k) { lo = mid; cnt_lo = c; } else { hi = mid - 1; cnt_hi = c; }
+        }
+        if (lo < hi) {
+            wave_lds_sync();   // every lane holds its keys in registers: the row in LDS becomes the candidate list
+            int base = 0;
+            const uint32_t span = hi - lo;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                const bool in = (kr[j] - lo) <= span && j < nj;
+                const unsigned long long bal = __ballot(in);
+                if (bal) {
+                    if (in) krow[base + (int)__popcll(bal & lanes_below(lane))] = kr[j];
+                    base += (int)__popcll(bal);
+                }
+            }
+            wave_lds_sync();
+            const bool valid = lane < base;
+            const uint32_t mine = valid ? krow[lane] : 0u;
+            while (lo < hi) {
+                const uint32_t mid = lo + ((hi - lo) >> 1) + 1;
+                if (cnt_hi + (int)__popcll(__ballot(valid && mine >= mid)) >= k) lo = mid; else hi = mid - 1;
+            }
+        }
+        const uint32_t T = lo;
         int c = 0;
 #pragma unroll
         for (int j = 0; j < 32; ++j) c += (kr[j] > T) ? 1 : 0;
@@ -234,7 +289,7 @@ __device__ __forceinline__ void topk_walk(const uint32_t* krow, int Cp, int k, i
 }
 
 // Top-k of one row as a C-bit bitmap (uint32 words, Cp/32 of them); one full wave.
-__device__ __forceinline__ void topk_bitmap(const uint32_t* krow, int Cp, int k, uint32_t* bits, int lane) {
+__device__ __forceinline__ void topk_bitmap(uint32_t* krow, int Cp, int k, uint32_t* bits, int lane) {
     topk_walk(krow, Cp, k, lane, [&](int j, uint32_t, bool, unsigned long long sel) {
         if (lane == 0) {
             bits[2 * j] = (uint32_t)sel;
@@ -245,7 +300,7 @@ __device__ __forceinline__ void topk_bitmap(const uint32_t* krow, int Cp, int k,
 
 // Top-k of one row, sorted descending (ties: ascending id) -> out[0..k); one full wave.
 // sortbuf: LDS, npow2 (>= k, power of two) uint64 entries owned by this wave.
-__device__ __forceinline__ void topk_sorted(const uint32_t* krow, int Cp, int k, int npow2,
+__device__ __forceinline__ void topk_sorted(uint32_t* krow, int Cp, int k, int npow2,
                                             unsigned long long* sortbuf, int32_t* out, int lane) {
     int base = 0;
     topk_walk(krow, Cp, k, lane, [&](int j, uint32_t key, bool take, unsigned long long sel) {
@@ -487,6 +542,18 @@ __device__ __forceinline__ void merge_state(float& m, float& l, float* o, int n,
 #define SPFA_LG1 2           // wave loads of K (and of V) per step, one-q-head kernels: short bursts keep the
                              // CU's memory queue shallow, so the selector wave's dependent loads return quickly
 #endif
+#ifndef SPFA_LGN
+#define SPFA_LGN 4           // the same for the kernels that hold up to 4 q heads (f16/bf16) per pass
+#endif
+#ifndef SPFA_MINWAVES_N
+#define SPFA_MINWAVES_N 2    // launch-bounds waves per SIMD of the 2..4-q-head kernels
+#endif
+#ifndef SPFA_EXPLORE_NQ
+#define SPFA_EXPLORE_NQ 1    // exploration builds instantiate one q-head count only
+#endif
+#ifndef SPFA_PRIO
+#define SPFA_PRIO 0          // wave priority of the streamer waves in the item loop (selector stays at 0)
+#endif
 #ifndef SPFA_KV_AUX
 #define SPFA_KV_AUX 2       // cache policy bits of the K/V buffer loads (2 = nt: read once, do not displace the
                              // centroids and tables from L2)
@@ -530,10 +597,10 @@ __device__ __forceinline__ int fetch_item(unsigned* counters, int xcd, int total
 }
 
 template <typename KVT, int NQ, int LPT>
-__global__ __launch_bounds__(kAttnThreads, (NQ == 1 ? SPFA_MINWAVES : (NQ <= 4 ? 2 : 1))) void attn_kernel(const AttnParams p) {
+__global__ __launch_bounds__(kAttnThreads, (NQ == 1 ? SPFA_MINWAVES : (NQ <= 4 ? SPFA_MINWAVES_N : 1))) void attn_kernel(const AttnParams p) {
     constexpr int EPL = KvTraits<KVT>::EPL;     // elements per 16-byte lane load
     constexpr int TPL = 64 / LPT;               // tokens per wave load
-    constexpr int LG = (NQ * EPL <= 16) ? SPFA_LG1 : ((NQ * EPL <= 32) ? 4 : 2);   // wave loads of K (and V) per step
+    constexpr int LG = (NQ * EPL <= 16) ? SPFA_LG1 : ((NQ * EPL <= 32) ? SPFA_LGN : 2);   // wave loads of K (and V) per step
     constexpr int STEP = TPL * LG;
     constexpr bool QUANT = sizeof(KVT) == 1;
     constexpr float kNegBig = -1.0e30f;
@@ -550,7 +617,8 @@ __global__ __launch_bounds__(kAttnThreads, (NQ == 1 ? SPFA_MINWAVES : (NQ <= 4 ?
     const int total = p.B * heads_per_b * n_pass;
 
     uint32_t* keys = (uint32_t*)(smem + p.off_keys);                              // [NQ][Cp]   (selector)
-    uint32_t* cbits = (uint32_t*)(smem + p.off_cbits);                            // [Cp/32]    (selector)
+    uint32_t* cbits = (uint32_t*)(smem + p.off_cbits);                            // [min(NQ,5)][Cp/32]
+    int* row_lens = (int*)(smem + p.off_pbits) - 8;                               // [8] list lengths of the first item
     unsigned long long* pbits_all = (unsigned long long*)(smem + p.off_pbits);    // [NQ][n_pwords] (selector)
     PageEntry* lists = (PageEntry*)(smem + p.off_list);                           // [2][max_entries]
     float* combs = (float*)(smem + p.off_comb);                                   // [2][4][NQ][D+2]
@@ -581,8 +649,27 @@ __global__ __launch_bounds__(kAttnThreads, (NQ == 1 ? SPFA_MINWAVES : (NQ <= 4 ?
         c.row0 = (long long)c.b * p.Hq + c.head0;
         return c;
     };
-    // item < 0: fetch the next one; scored: the keys of this item are already in LDS
-    auto build = [&](int slot, int item, bool scored) {
+    // top-k clusters of row r of an item -> its page list (outputs + LDS bitmap); returns the list length
+    auto select_row = [&](const ItemCtx& ctx, int r, uint32_t* cb, int page_len) {
+        topk_bitmap(keys + r * p.Cp, p.Cp, p.k, cb, lane);
+        wave_lds_sync();
+        SPFA_STAMP(3);
+        const long long row = ctx.row0 + r;
+        const int len = select_pages(cb, p.C, p.block_table + (long long)ctx.b * p.max_page,
+                                     p.block_ids + (long long)ctx.n2 * p.kv_page_len, p.kv_page_len, page_len, p.P,
+                                     p.sink_recent, p.cap_pages,
+                                     p.page_position ? p.page_position + row * p.P : nullptr,
+                                     pbits_all + (size_t)r * n_pwords, n_pwords, lane);
+        if (p.page_position_length && lane < kLenPad) p.page_position_length[row * kLenPad + lane] = len;
+        wave_lds_sync();
+        return len;
+    };
+    auto page_len_of = [&](int b) {
+        return max(0, min((p.seq_len[b] + p.block_size - 1) / p.block_size, p.max_page));
+    };
+    // item < 0: fetch the next one; stage: 0 nothing done yet, 1 the keys of this item are already in LDS,
+    // 2 the rows' page lists are done as well (bitmaps in pbits_all, lengths in row_lens)
+    auto build = [&](int slot, int item, int stage) {
         ItemHdr* hdr = hdrs + slot;
         PageEntry* list = lists + (size_t)slot * p.max_entries;
         float* qst = qsts + (size_t)slot * NQ * D;
@@ -600,24 +687,13 @@ __global__ __launch_bounds__(kAttnThreads, (NQ == 1 ? SPFA_MINWAVES : (NQ <= 4 ?
         int nU = 0;
         if (p.mode == 1) {
             const int seq = p.seq_len[b];
-            const int page_len = max(0, min((seq + p.block_size - 1) / p.block_size, p.max_page));
-            if (!scored) score_rows<1>(p.q, p.cent, p.q_dtype, row0, n2, R, D, p.C, p.Cp, keys);
+            const int page_len = page_len_of(b);
+            if (stage < 1) score_rows<1>(p.q, p.cent, p.q_dtype, row0, n2, R, D, p.C, p.Cp, keys);
             wave_lds_sync();
             SPFA_STAMP(2);
             int len_max = 0;
-            for (int r = 0; r < R; ++r) {
-                topk_bitmap(keys + r * p.Cp, p.Cp, p.k, cbits, lane);
-                wave_lds_sync();
-                SPFA_STAMP(3);
-                const long long row = row0 + r;
-                const int len = select_pages(cbits, p.C, bt_row, p.block_ids + (long long)n2 * p.kv_page_len,
-                                             p.kv_page_len, page_len, p.P, p.sink_recent, p.cap_pages,
-                                             p.page_position ? p.page_position + row * p.P : nullptr,
-                                             pbits_all + (size_t)r * n_pwords, n_pwords, lane);
-                if (p.page_position_length && lane < kLenPad) p.page_position_length[row * kLenPad + lane] = len;
-                len_max = max(len_max, len);
-                wave_lds_sync();
-            }
+            for (int r = 0; r < R; ++r)
+                len_max = max(len_max, stage < 2 ? select_row(ctx, r, cbits, page_len) : row_lens[r]);
             if (p.max_page_position_length && lane < kLenPad && len_max > 0)   // cent_select.cpp:124-152
                 atomicMax(p.max_page_position_length + (long long)b * kLenPad + lane,
                           (unsigned long long)len_max * (unsigned long long)p.block_size);
@@ -862,12 +938,22 @@ __global__ __launch_bounds__(kAttnThreads, (NQ == 1 ? SPFA_MINWAVES : (NQ <= 4 ?
     int slot = 0;
     {
         const int item0 = (int)blockIdx.x;   // grid <= total
+        int stage0 = 1;
         if (p.mode == 1) {
             const ItemCtx c0 = decode(item0);
             score_rows<kStreamWaves + 1>(p.q, p.cent, p.q_dtype, c0.row0, c0.n2, c0.R, D, p.C, p.Cp, keys);
             __syncthreads();
+            if (NQ > 1 && c0.R > 1) {   // one wave per row instead of the selector walking all of them
+                const int page_len = page_len_of(c0.b);
+                for (int r = wave; r < c0.R; r += kStreamWaves + 1) {
+                    const int len = select_row(c0, r, cbits + (size_t)wave * (p.Cp >> 5), page_len);
+                    if (lane == 0) row_lens[r] = len;
+                }
+                __syncthreads();
+                stage0 = 2;
+            }
         }
-        if (selector) build(0, item0, true);
+        if (selector) build(0, item0, stage0);
     }
     __syncthreads();
 #ifdef SPFA_STAMPS
@@ -875,6 +961,10 @@ __global__ __launch_bounds__(kAttnThreads, (NQ == 1 ? SPFA_MINWAVES : (NQ <= 4 ?
 #endif
     int prev_row0 = 0, prev_R = 0, prev_n2 = 0;
     bool have_prev = false;
+#if SPFA_PRIO
+    // the streamers' issue slots come first; the selector wave works in the gaps they leave
+    if (!selector) __builtin_amdgcn_s_setprio(SPFA_PRIO);
+#endif
     while (true) {
         const int item = __builtin_amdgcn_readfirstlane(hdrs[slot].item);
         const int nU = __builtin_amdgcn_readfirstlane(hdrs[slot].nU);
@@ -883,7 +973,7 @@ __global__ __launch_bounds__(kAttnThreads, (NQ == 1 ? SPFA_MINWAVES : (NQ <= 4 ?
         const int R = __builtin_amdgcn_readfirstlane(hdrs[slot].R);
         if (have_prev && !selector) finalize(slot ^ 1, prev_row0, prev_R, prev_n2);
         if (item < 0) break;
-        if (selector) build(slot ^ 1, -1, false);
+        if (selector) build(slot ^ 1, -1, 0);
         else {
             if (wave == 0) SPFA_STAMP(8);
             stream(slot, nU, n2);
@@ -953,8 +1043,10 @@ hipError_t launch_attn_lpt(const AttnParams& p, int lpt, hipStream_t s) {
 template <typename KVT>
 hipError_t launch_attn_nq(const AttnParams& p, int nq, int lpt, hipStream_t s) {
     switch (nq) {
+#ifdef SPFA_EXPLORE
+        case SPFA_EXPLORE_NQ: return launch_attn_lpt<KVT, SPFA_EXPLORE_NQ>(p, lpt, s);
+#else
         case 1: return launch_attn_lpt<KVT, 1>(p, lpt, s);
-#ifndef SPFA_EXPLORE
         case 4: return launch_attn_lpt<KVT, 4>(p, lpt, s);
         case 8: return launch_attn_lpt<KVT, 8>(p, lpt, s);
 #endif

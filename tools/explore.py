@@ -54,8 +54,11 @@ def main():
     def attn(k, v):
         return custom_ops.sparse_paged_attention(wl["q"], k, v, e, e, act, e, e, e, e, e, asc, aof, wl["table"], ei,
                                                  pos, Hq, D ** -0.5, "BNSD", Hkv, bs, 1)
-    t_at = timeit(lambda: attn(wl["key"], wl["val"]))
-    print(f"attention BSH    {t_at*1e3:8.1f} us  {gbytes/t_at/1e6:8.1f} GB/s")
+    try:
+        t_at = timeit(lambda: attn(wl["key"], wl["val"]))
+        print(f"attention BSH    {t_at*1e3:8.1f} us  {gbytes/t_at/1e6:8.1f} GB/s")
+    except RuntimeError as ex:   # exploration builds hold one instantiation only
+        print("attention BSH    n/a:", str(ex)[:60])
     if os.environ.get("EXPLORE_BNSD", "1") == "1":
         kb = wl["key"].permute(0, 2, 1, 3).contiguous()
         vb = wl["val"].permute(0, 2, 1, 3).contiguous()

@@ -7,7 +7,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 var_dir = os.path.join(ROOT, "cann-ops-adv-vllm_amd", "lib_var")
 names = sys.argv[1].split(",") if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else sorted(os.listdir(var_dir))
-extra = [a for a in sys.argv[1:] if a.startswith("-")]
+extra = sys.argv[2:] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else sys.argv[1:]
 for n in names:
     lib = os.path.join(var_dir, n, "libcust_opapi.so")
     if not os.path.exists(lib):
