@@ -1,0 +1,176 @@
+"""Full-size parity on the GPU: the BASELINE shapes (64 sequences per GPU), checked through
+  * size-independent properties computed with plain torch ops on the device (no oracle involved):
+    selected pages == pages whose cluster id is in the row's top-k set, rows ascending and sentinel padded,
+    lengths and per-batch maxima consistent, fused == cent_select + sparse_paged_attention
+    (the reference's own identity, fused_ifa_v5_case.py:215-276), exact scaling of V by a power of two,
+    constant-V known answer (tests/ifa_v5_case.py:53-59);
+  * the CPU oracle (oracle/oracle.c) on a sample of sequences whose KV pages are copied to the host.
+Integer outputs must match bit for bit; attention within 1e-3 relative (fp32 output).
+"""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+import bench
+import custom_ops
+from gpu_helpers import DEV, empty
+
+pytestmark = pytest.mark.gpu
+
+SENTINEL = 0x7FFFFFFF
+REL_TOL = 1e-3   # BASELINE: attention_out within 1e-3 relative
+
+
+def args(**kw):
+    a = argparse.Namespace(gpus=1, steps=1, warmup=0, batch=64, heads=32, kv_heads=32, head_dim=128, seqlen=32768,
+                           clusters=2048, topk=32, block_size=128, kv="f16", no_cpu_baseline=True,
+                           cpu_sample_batch=2, seed=77)
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
+
+
+def run_fused(a, wl, out_dtype=torch.float32, val=None):
+    B, Hq = a.batch, a.heads
+    e = empty(wl["q"].dtype)
+    pos = torch.empty((B, Hq, 256), dtype=torch.int32, device=DEV)
+    plen = torch.empty((B, Hq, 8), dtype=torch.int32, device=DEV)
+    pmax = torch.empty((B, 8), dtype=torch.int64, device=DEV)
+    out, _, _ = custom_ops.sparse_paged_fusion_attention(
+        wl["q"], wl["key"], wl["val"] if val is None else val, e, e, [a.seqlen // 8], e, e, e, e, e,
+        wl["a_scale"] if wl["a_scale"] is not None else e, wl["a_off"] if wl["a_off"] is not None else e,
+        wl["table"], empty(torch.int64), wl["l1"], wl["block_ids"], wl["seq"], pos, plen, pmax,
+        Hq, a.head_dim ** -0.5, "BNSD", a.kv_heads, a.block_size, 1, k=a.topk, out_dtype=out_dtype)
+    return out, pos, plen, pmax
+
+
+def check_selection_properties(a, wl, pos, plen, pmax):
+    """page_position against the definition, evaluated with torch ops from compute_cent's indices."""
+    B, Hq, Hkv, bs = a.batch, a.heads, a.kv_heads, a.block_size
+    G = Hq // Hkv
+    page_len = wl["page_len"]
+    P = pos.shape[2]
+    idx = custom_ops.compute_cent(wl["q"], wl["l1"], k=a.topk).long()              # [B,Hq,k]
+    in_topk = torch.zeros((B, Hq, a.clusters), dtype=torch.bool, device=DEV)
+    in_topk.scatter_(2, idx, True)
+    assert int(in_topk.sum()) == B * Hq * a.topk                                   # k distinct ids per row
+    phys = wl["table"].long()                                                      # [B,page_len]
+    cid = wl["block_ids"].long()[:, phys]                                          # [Hkv,B,page_len]
+    cid = cid.permute(1, 0, 2).repeat_interleave(G, dim=1)                         # [B,Hq,page_len]
+    member = in_topk.gather(2, cid)                                                # page selected?
+    count = member.sum(dim=2)
+    length = torch.clamp(count, max=P).to(torch.int32)
+    assert torch.equal(plen, length.unsqueeze(-1).expand(-1, -1, 8))
+    assert torch.equal(pmax, (length.max(dim=1).values.long() * bs).unsqueeze(-1).expand(-1, 8))
+    slots = torch.arange(P, device=DEV)[None, None, :]
+    live = slots < length.unsqueeze(-1)
+    assert bool((pos[~live] == SENTINEL).all())
+    # ascending, in range, and exactly the member pages (first P of them)
+    p = torch.where(live, pos, torch.full_like(pos, page_len)).long()
+    assert bool((p[:, :, 1:] > p[:, :, :-1])[live[:, :, 1:]].all())
+    assert bool((p[live] < page_len).all()) and bool((p[live] >= 0).all())
+    got = torch.zeros((B, Hq, page_len + 1), dtype=torch.bool, device=DEV)
+    got.scatter_(2, p, True)
+    rank = member.cumsum(dim=2)
+    want = member & (rank <= P)
+    assert torch.equal(got[:, :, :page_len], want)
+    return idx
+
+
+def check_against_oracle(a, wl, out, pos, plen, pmax, seqs):
+    want_out, want_pos, want_len, want_max = bench.host_sample(a, wl, seqs)()
+    s = torch.as_tensor(seqs, device=DEV)
+    assert np.array_equal(pos[s].cpu().numpy(), want_pos)
+    assert np.array_equal(plen[s].cpu().numpy(), want_len)
+    assert np.array_equal(pmax[s].cpu().numpy(), want_max)
+    got = out[s].float().cpu().numpy()
+    denom = np.maximum(np.abs(want_out), 1e-2 * np.abs(want_out).max())
+    err = float((np.abs(got - want_out) / denom).max())
+    assert err <= REL_TOL, err
+
+
+def check_fused_equals_separate(a, wl, out, pos, plen, pmax):
+    e = empty(wl["q"].dtype)
+    pos2, plen2, pmax2 = custom_ops.cent_select(wl["q"], wl["l1"], wl["block_ids"], wl["table"], wl["seq"], k=a.topk,
+                                                page_size=a.block_size)
+    assert torch.equal(pos, pos2) and torch.equal(plen, plen2) and torch.equal(pmax, pmax2)
+    out2 = custom_ops.sparse_paged_attention(
+        wl["q"], wl["key"], wl["val"], e, e, pmax[:, 0].contiguous(), e, e, e, e, e,
+        wl["a_scale"] if wl["a_scale"] is not None else e, wl["a_off"] if wl["a_off"] is not None else e,
+        wl["table"], empty(torch.int64), pos, a.heads, a.head_dim ** -0.5, "BNSD", a.kv_heads, a.block_size, 1,
+        out_dtype=torch.float32)
+    # per-q-head lists walk each head's pages alone, the fused op walks the union of a group: the page order
+    # inside a head's list is the same, the split into partial softmax states is not
+    scale = float(out.abs().max())
+    assert float((out - out2).abs().max()) <= 2e-5 * scale
+
+
+def test_c3_f16_mha_full_size():
+    a = args()
+    wl = bench.build_workload(a, torch.device(DEV), a.batch, a.seed, custom_ops)
+    out, pos, plen, pmax = run_fused(a, wl)
+    assert int(plen[:, :, 0].min()) == 32 and int(plen[:, :, 0].max()) == 32     # the budgeted workload: pageLen/8
+    check_selection_properties(a, wl, pos, plen, pmax)
+    check_fused_equals_separate(a, wl, out, pos, plen, pmax)
+    check_against_oracle(a, wl, out, pos, plen, pmax, [0, a.batch - 1])
+    # V -> 2V doubles the fp32 output exactly (power-of-two scaling commutes with every rounding on the way)
+    wl["val"].mul_(2)
+    out2, pos2, _, _ = run_fused(a, wl)
+    assert torch.equal(pos, pos2)
+    assert torch.equal(out2, out * 2)
+    # constant V: the output is that constant whatever was selected
+    wl["val"].fill_(0.375)
+    out3, _, _, _ = run_fused(a, wl)
+    assert float((out3 - 0.375).abs().max()) <= 5e-6
+    # f16 output == the fp32 result rounded once
+    wl["val"].uniform_(1e-3, 1.0)
+    o32, _, _, _ = run_fused(a, wl)
+    o16, _, _, _ = run_fused(a, wl, out_dtype=None)
+    assert o16.dtype == torch.float16 and torch.equal(o16, o32.to(torch.float16))
+    del wl
+    torch.cuda.empty_cache()
+
+
+def test_c4_int8_kv_64k_full_size():
+    a = args(seqlen=65536, kv="int8")
+    wl = bench.build_workload(a, torch.device(DEV), a.batch, a.seed, custom_ops)
+    out, pos, plen, pmax = run_fused(a, wl)
+    assert int(plen[:, :, 0].min()) == 64
+    check_selection_properties(a, wl, pos, plen, pmax)
+    check_fused_equals_separate(a, wl, out, pos, plen, pmax)
+    check_against_oracle(a, wl, out, pos, plen, pmax, [3, 40])
+    del wl
+    torch.cuda.empty_cache()
+
+
+def test_c5_gqa_128k_one_gpu_share():
+    """BASELINE configs[4] per GPU: 64 of the 512 sequences, Hq=32 / Hkv=8, 128k tokens, k=64."""
+    a = args(kv_heads=8, seqlen=131072, topk=64)
+    wl = bench.build_workload(a, torch.device(DEV), a.batch, a.seed, custom_ops)
+    out, pos, plen, pmax = run_fused(a, wl)
+    check_selection_properties(a, wl, pos, plen, pmax)
+    check_fused_equals_separate(a, wl, out, pos, plen, pmax)
+    check_against_oracle(a, wl, out, pos, plen, pmax, [17])
+    del wl
+    torch.cuda.empty_cache()
+
+
+def test_ragged_lengths_bf16_gqa_full_batch():
+    """Ragged total_seq_len (1 token .. full), bf16, GQA-4: selection properties, the oracle on a sample."""
+    a = args(kv_heads=8, seqlen=16384, kv="bf16", clusters=1024)
+    wl = bench.build_workload(a, torch.device(DEV), a.batch, a.seed, custom_ops)
+    g = torch.Generator(device=DEV)
+    g.manual_seed(5)
+    seq = torch.randint(1, a.seqlen + 1, (a.batch,), generator=g, device=DEV, dtype=torch.int32)
+    seq[0], seq[1], seq[2] = 1, a.seqlen, a.block_size + 1
+    wl["seq"] = seq
+    out, pos, plen, pmax = run_fused(a, wl)
+    check_against_oracle(a, wl, out, pos, plen, pmax, [0, 1, 2, 30])
+    # every stored page index lies inside its sequence
+    page_len = (seq.long() + a.block_size - 1) // a.block_size
+    live = torch.arange(256, device=DEV)[None, None, :] < plen[:, :, :1]
+    assert bool((pos.long()[live] < page_len[:, None, None].expand(-1, a.heads, 256)[live]).all())
+    del wl
+    torch.cuda.empty_cache()

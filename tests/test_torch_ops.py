@@ -1,0 +1,79 @@
+"""`torch.ops.myops.*`: the dispatcher-level surface (extension/csrc/registration.cpp:43-57) exists, refuses CPU
+tensors (there is no CPU implementation) and, on the GPU, returns what `custom_ops.*` returns."""
+import numpy as np
+import pytest
+import torch
+
+import custom_ops  # noqa: F401  (registers the schemas)
+import datagen
+
+OPS = ("compute_cent", "select_position", "cent_select", "sparse_paged_attention", "sparse_paged_fusion_attention")
+
+
+def test_schemas_follow_the_reference():
+    for name in OPS:
+        assert hasattr(torch.ops.myops, name)
+    s = torch.ops.myops.sparse_paged_fusion_attention.default._schema
+    names = [a.name for a in s.arguments]
+    assert names[:3] == ["query", "key_list", "value_list"]
+    assert names[15:21] == ["l1_cent", "block_ids", "total_seq_len", "block_position", "page_position_length",
+                            "max_page_position_length"]
+    assert names[21:] == ["num_heads", "scale_value", "input_layout", "num_key_value_heads", "block_size",
+                          "inner_precise"]
+    assert len(s.returns) == 3
+    s = torch.ops.myops.sparse_paged_attention.default._schema
+    assert [a.name for a in s.arguments][13:16] == ["blocktable", "kv_padding_size", "blockposition"]
+
+
+def test_cpu_tensors_are_refused():
+    q = torch.zeros((2, 8, 64), dtype=torch.float16)
+    c = torch.zeros((2, 256, 64), dtype=torch.float16)
+    with pytest.raises(NotImplementedError):
+        torch.ops.myops.compute_cent(q, c)
+    with pytest.raises(RuntimeError):
+        custom_ops.compute_cent(q, c)
+
+
+@pytest.mark.gpu
+def test_dispatcher_ops_equal_python_ops():
+    dev = "cuda:0"
+    B, Hq, Hkv, D, C, bs, pages = 3, 8, 2, 128, 256, 128, 24
+    q, l1 = datagen.cent_case(11, B, Hq, Hkv, D, C)
+    n_blocks = B * pages
+    block_ids, table, seq = datagen.page_case(11, Hkv, C, n_blocks, B, pages, [pages * bs, 5 * bs + 3, 1],
+                                              aliasing=False)
+    k_np, v_np = datagen.kv_case(11, n_blocks, bs, Hkv, D, "BSH")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    q, l1, block_ids, table, seq, key, val = map(t, (q, l1, block_ids, table, seq, k_np, v_np))
+    e = torch.empty(0, dtype=torch.float16, device=dev)
+    ei = torch.empty(0, dtype=torch.int64, device=dev)
+
+    idx = torch.ops.myops.compute_cent(q, l1)
+    assert torch.equal(idx, custom_ops.compute_cent(q, l1))
+    a = torch.ops.myops.select_position(block_ids, table, seq, idx)
+    b = custom_ops.select_position(block_ids, table, seq, idx)
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    a = torch.ops.myops.cent_select(q, l1, block_ids, table, seq)
+    b = custom_ops.cent_select(q, l1, block_ids, table, seq)
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    pos, plen, pmax = b
+
+    act = pmax[:, 0].contiguous()
+    o1 = torch.ops.myops.sparse_paged_attention(q, [key], [val], e, e, act, e, e, e, e, e, e, e, table, ei, pos,
+                                                Hq, D ** -0.5, "BNSD", Hkv, bs, 1)
+    o2 = custom_ops.sparse_paged_attention(q, key, val, e, e, act, e, e, e, e, e, e, e, table, ei, pos,
+                                           Hq, D ** -0.5, "BNSD", Hkv, bs, 1)
+    assert torch.equal(o1, o2)
+
+    def fused(fn, kv):
+        p = torch.empty((B, Hq, 256), dtype=torch.int32, device=dev)
+        n = torch.empty((B, Hq, 8), dtype=torch.int32, device=dev)
+        m = torch.empty((B, 8), dtype=torch.int64, device=dev)
+        out, p2, m2 = fn(q, kv(key), kv(val), e, e, torch.tensor([pages * bs // 8]), e, e, e, e, e, e, e, table, ei,
+                         l1, block_ids, seq, p, n, m, Hq, D ** -0.5, "BNSD", Hkv, bs, 1)
+        assert p2.data_ptr() == p.data_ptr() and m2.data_ptr() == m.data_ptr()
+        return out, p, n, m
+    a = fused(torch.ops.myops.sparse_paged_fusion_attention, lambda x: [x])
+    b = fused(custom_ops.sparse_paged_fusion_attention, lambda x: x)
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    assert torch.equal(a[1], pos) and torch.equal(a[2], plen) and torch.equal(a[3], pmax)
