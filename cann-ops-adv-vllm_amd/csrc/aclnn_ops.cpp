@@ -532,31 +532,41 @@ static aclnnStatus plan_attention(spfa::AttnParams& p, const aclTensor* query, c
 
 constexpr uint64_t kCounterBytes = 256;   // 8 work counters at the start of the workspace, zeroed per launch
 
-static aclnnStatus plan_lds(spfa::AttnParams& p) {
-    const bool per_head = (p.mode == 0 && p.pos_rows == p.Hq && p.G > 1);
-    p.rows_per_pass = per_head ? 1 : spfa::attention_rows_per_pass(p.G, p.kv_dtype);
-    const size_t nq = (size_t)p.rows_per_pass;
+static size_t carve_lds(spfa::AttnParams& p, size_t nq) {
     auto align16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
     size_t off = 0;
     p.off_keys = (int)off;
-    if (p.mode == 1) {
-        REQUIRE(nq * p.Cp * 4 <= 96 * 1024, "cluster count %d too large for the fused kernel", p.C);
-        off += align16(nq * p.Cp * 4);                                     // score keys (selector wave)
-    }
+    if (p.mode == 1) off += align16(nq * p.Cp * 4);                        // score keys (selector wave)
     p.off_cbits = (int)off;
-    if (p.mode == 1)   // top-k cluster bitmaps (one per wave that selects a row of the first item) + 8 row lengths
-        off += align16((nq < 5 ? nq : 5) * (size_t)(p.Cp / 32) * 4) + 32;
+    if (p.mode == 1)   // top-k cluster bitmaps (one per wave that selects a row of the first item) + 16 row lengths
+        off += align16((nq < 6 ? nq : 6) * (size_t)(p.Cp / 32) * 4) + 64;
     p.off_pbits = (int)off;
     if (p.mode == 1) off += align16(nq * ((p.max_page + 63) / 64) * 8);    // per-head page bitmaps
     p.off_list = (int)off;
-    off += align16((size_t)2 * p.max_entries * 16);                        // double-buffered page lists
+    off += align16((size_t)2 * p.max_entries * 8);                         // double-buffered page lists
     p.off_comb = (int)off;
     off += align16((size_t)2 * 4 * nq * (p.D + 2) * 4);                    // streamer states of two items
     p.off_qst = (int)off;
-    off += align16((size_t)2 * nq * p.D * 4);                              // pre-scaled q rows
+    const bool mfma = spfa::attention_uses_mfma((int)nq, p.kv_dtype);
+    if (!mfma) off += align16((size_t)2 * nq * p.D * 4);                   // pre-scaled q rows (VALU streamer)
     p.off_hdr = (int)off;
-    off += 2 * 32;
-    p.lds_bytes = off;
+    off += 2 * 32 + 16;                                                    // two item headers + selector team words
+    p.off_vst = (int)off;
+    if (mfma) off += (size_t)4 * 32 * (p.D * 2 + 32);                      // V tile images of the 4 streamer waves
+    return off;
+}
+
+static aclnnStatus plan_lds(spfa::AttnParams& p) {
+    const bool per_head = (p.mode == 0 && p.pos_rows == p.Hq && p.G > 1);
+    int nq = per_head ? 1 : spfa::attention_rows_per_pass(p.G, p.kv_dtype);
+    size_t need = carve_lds(p, (size_t)nq);
+    // a large group with many clusters: fewer q heads per pass (more passes over the pages) until the keys fit
+    while (need > kMaxLds && nq > 2 && spfa::attention_uses_mfma(nq, p.kv_dtype)) {
+        nq = (nq + 1) / 2;
+        need = carve_lds(p, (size_t)nq);
+    }
+    p.rows_per_pass = nq;
+    p.lds_bytes = need;
     REQUIRE(p.lds_bytes <= kMaxLds, "page list of %d entries / %d clusters needs %zu bytes of LDS (> %zu)", p.max_entries,
             p.C, p.lds_bytes, kMaxLds);
     return ACLNN_SUCCESS;

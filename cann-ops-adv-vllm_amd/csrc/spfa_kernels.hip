@@ -90,11 +90,10 @@ __device__ __forceinline__ float load_qk_elem(const void* p, int dtype, long lon
 // the store), so one round trip to L2 brings 16 KiB per wave instead of 1 KiB.
 template <int WAVES, bool BF16, int KS>
 __device__ __forceinline__ void score_rows_impl(const void* q, const void* cent, long long q_row0, int n2, int R,
-                                                int C, int Cp, uint32_t* keys) {
+                                                int C, int Cp, uint32_t* keys, int wave) {
     constexpr int D = KS * 32;
     constexpr int TG = 16 / KS;   // tiles per group: TG * KS = 16 loads in flight
     const int lane = lane_id();
-    const int wave = WAVES == 1 ? 0 : wave_id();
     const int col = lane & 15;   // A: q row of the tile, B: centroid of the tile
     const int kq = lane >> 4;    // which 8-wide slice of the 32-deep k step
     uint4 qa[KS];
@@ -136,13 +135,14 @@ __device__ __forceinline__ void score_rows_impl(const void* q, const void* cent,
     }
 }
 
+// widx: this wave's index among the WAVES waves that share the tiles.
 template <int WAVES>
 __device__ __forceinline__ void score_rows(const void* q, const void* cent, int dtype, long long q_row0,
-                                           int n2, int R, int D, int C, int Cp, uint32_t* keys) {
+                                           int n2, int R, int D, int C, int Cp, uint32_t* keys, int widx) {
 #define SPFA_SCORE(KS)                                                                              \
     case KS:                                                                                        \
-        if (dtype == kBF16) score_rows_impl<WAVES, true, KS>(q, cent, q_row0, n2, R, C, Cp, keys);  \
-        else score_rows_impl<WAVES, false, KS>(q, cent, q_row0, n2, R, C, Cp, keys);                \
+        if (dtype == kBF16) score_rows_impl<WAVES, true, KS>(q, cent, q_row0, n2, R, C, Cp, keys, widx);  \
+        else score_rows_impl<WAVES, false, KS>(q, cent, q_row0, n2, R, C, Cp, keys, widx);                \
         break;
     switch (D >> 5) {
         SPFA_SCORE(1)
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(kThreads) void cent_kernel(const CentParams p) {
     for (int g0 = 0; g0 < p.G; g0 += RG) {
         const int R = min(RG, p.G - g0);
         const long long row0 = (long long)b * p.Hq + (long long)n2 * p.G + g0;
-        score_rows<4>(p.q, p.cent, p.qk_dtype, row0, n2, R, p.D, p.C, p.Cp, keys);
+        score_rows<4>(p.q, p.cent, p.qk_dtype, row0, n2, R, p.D, p.C, p.Cp, keys, wave);
         __syncthreads();
         for (int r = wave; r < R; r += 4) {
             const long long row = row0 + r;
@@ -482,10 +482,10 @@ __global__ __launch_bounds__(kThreads) void select_position_kernel(const SelectP
 //   keep their centroids in that XCD's L2; a workgroup whose class is exhausted steals from the others,
 //   so every item is processed whatever the placement.
 // ------------------------------------------------------------------------------------------------
-struct PageEntry {            // 16 bytes in LDS
+struct PageEntry {            // 8 bytes in LDS
     int phys;                 // physical block
-    int valid;                // attended tokens of the page
-    unsigned long long mask;  // bit g: head g of the pass attends this page
+    unsigned short valid;     // attended tokens of the page (<= 512)
+    unsigned short mask;      // bit g: head g of the pass attends this page (<= 16 heads per pass)
 };
 struct ItemHdr {              // 32 bytes in LDS
     int item;                 // < 0: no more work
@@ -548,8 +548,8 @@ __device__ __forceinline__ void merge_state(float& m, float& l, float* o, int n,
 #ifndef SPFA_MINWAVES_N
 #define SPFA_MINWAVES_N 2    // launch-bounds waves per SIMD of the 2..4-q-head kernels
 #endif
-#ifndef SPFA_EXPLORE_NQ
-#define SPFA_EXPLORE_NQ 1    // exploration builds instantiate one q-head count only
+#ifndef SPFA_MFMA_PREFETCH
+#define SPFA_MFMA_PREFETCH 1 // MFMA streamer: issue the next tile's loads before computing the current one
 #endif
 #ifndef SPFA_PRIO
 #define SPFA_PRIO 0          // wave priority of the streamer waves in the item loop (selector stays at 0)
@@ -560,9 +560,6 @@ __device__ __forceinline__ void merge_state(float& m, float& l, float* o, int n,
 #endif
 #ifndef SPFA_WGS_PER_CU
 #define SPFA_WGS_PER_CU 2     // resident workgroups per CU of the persistent grid (upper bound)
-#endif
-#ifndef SPFA_BUFLOAD
-#define SPFA_BUFLOAD 1       // 1: buffer loads with scalar offsets, 0: global loads
 #endif
 // Diagnostic builds (-DSPFA_STAMPS) record s_memtime stamps of the item pipeline into AttnParams::debug;
 // the shipped kernel contains none of this.
@@ -576,7 +573,10 @@ __device__ __forceinline__ void merge_state(float& m, float& l, float* o, int n,
 #define SPFA_STAMP(slotidx) do {} while (0)
 #endif
 constexpr int kStreamWaves = 4;
-constexpr int kAttnThreads = 64 * (kStreamWaves + 1);
+// Selector waves per workgroup: one where a single q head is selected per item; two where a pass carries a
+// whole GQA group (several rows to select for one page stream), so that selection stays hidden behind the stream.
+constexpr int sel_waves(bool mfma) { return mfma ? 2 : 1; }
+constexpr int attn_threads(bool mfma) { return 64 * (kStreamWaves + sel_waves(mfma)); }
 
 // Pull the next work item.  Class c holds items c, c+8, ...; start with this XCD's class.
 // The first item of every workgroup is static (item = blockIdx.x, which is the (blockIdx.x / 8)-th item of
@@ -596,34 +596,381 @@ __device__ __forceinline__ int fetch_item(unsigned* counters, int xcd, int total
     return __builtin_amdgcn_readfirstlane(item);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Streamer, VALU form (one q head per pass, and int8 KV): K/V pages of one item -> this wave's partial
+// softmax state in LDS.  list / qst / comb are the item's page list, pre-scaled q rows [NQ][D] and the
+// [4 waves][NQ][D + 2] state area.
+// ------------------------------------------------------------------------------------------------
 template <typename KVT, int NQ, int LPT>
-__global__ __launch_bounds__(kAttnThreads, (NQ == 1 ? SPFA_MINWAVES : (NQ <= 4 ? SPFA_MINWAVES_N : 1))) void attn_kernel(const AttnParams p) {
+__device__ __forceinline__ void stream_valu(const AttnParams& p, const PageEntry* list, const float* qst, float* comb,
+                                            int nU, int n2, int lane, int wave) {
     constexpr int EPL = KvTraits<KVT>::EPL;     // elements per 16-byte lane load
     constexpr int TPL = 64 / LPT;               // tokens per wave load
     constexpr int LG = (NQ * EPL <= 16) ? SPFA_LG1 : ((NQ * EPL <= 32) ? SPFA_LGN : 2);   // wave loads of K (and V) per step
     constexpr int STEP = TPL * LG;
     constexpr bool QUANT = sizeof(KVT) == 1;
     constexpr float kNegBig = -1.0e30f;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = lane_id(), wave = wave_id();
-    const bool selector = wave == kStreamWaves;
     const int sub = lane % LPT;                 // 16-byte slice of the head row
     const int grp = lane / LPT;                 // token within a wave load
     const int D = p.D;
+    const int cstride = D + 2;
+    float qf[NQ][EPL];
+    float qbias[NQ];   // int8: 128 * sum of this lane's q' (u = x + 128)
+#pragma unroll
+    for (int g = 0; g < NQ; ++g) {
+        qbias[g] = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            qf[g][e] = qst[g * D + sub * EPL + e];
+            qbias[g] += 128.f * qf[g][e];
+        }
+    }
+    float o[NQ][EPL], m[NQ], l[NQ];
+#pragma unroll
+    for (int g = 0; g < NQ; ++g) {
+        m[g] = kNegBig;
+        l[g] = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) o[g][e] = 0.f;
+    }
+    // Addressing: one buffer descriptor per page and head (uniform, SGPRs) + a per-lane byte offset
+    // that never changes (token group * token stride + 16-byte slice) + a scalar offset per wave
+    // load.  The descriptor's range ends at the last live row of this head in the page, so token slots past the
+    // page's live tokens read zeros instead of faulting or picking up whatever the cache holds there (a NaN
+    // bit pattern in a dead V row would otherwise poison 0 * v).
+    const int lane_off = grp * (int)p.tok_stride + sub * 16;
+    const int row_bytes = D * (int)sizeof(KVT);
+    for (int n = wave; n < nU; n += kStreamWaves) {
+        const int phys = __builtin_amdgcn_readfirstlane(list[n].phys);
+        const int valid = __builtin_amdgcn_readfirstlane(list[n].valid);
+        const unsigned mask = __builtin_amdgcn_readfirstlane((unsigned)list[n].mask);
+        const long long off = (long long)phys * p.blk_stride + (long long)n2 * p.head_stride;
+        const int page_range = (valid - 1) * (int)p.tok_stride + row_bytes;
+        const __amdgpu_buffer_rsrc_t rk =
+            __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.kcache + off), 0, page_range, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rv =
+            __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.vcache + off), 0, page_range, 0x00020000);
+        for (int t0 = 0; t0 < valid; t0 += STEP) {
+            uint4 kreg[LG], vreg[LG];
+#pragma unroll
+            for (int i = 0; i < LG; ++i)
+                kreg[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                        rk, lane_off, (t0 + i * TPL) * (int)p.tok_stride, SPFA_KV_AUX));
+#pragma unroll
+            for (int i = 0; i < LG; ++i)
+                vreg[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                        rv, lane_off, (t0 + i * TPL) * (int)p.tok_stride, SPFA_KV_AUX));
+            float s[NQ][LG];
+#pragma unroll
+            for (int i = 0; i < LG; ++i) {
+                float kf[EPL];
+                unpack16<KVT>(kreg[i], kf);
+                const bool live = (t0 + i * TPL + grp) < valid;
+#pragma unroll
+                for (int g = 0; g < NQ; ++g) {
+                    float acc = QUANT ? -qbias[g] : 0.f;
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) acc = fmaf(qf[g][e], kf[e], acc);
+                    acc = group_allsum<LPT>(acc);
+                    s[g][i] = live ? acc : -INFINITY;
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < NQ; ++g) {
+                if (!((mask >> g) & 1u)) {   // wave-uniform: this head does not attend the page
+#pragma unroll
+                    for (int i = 0; i < LG; ++i) s[g][i] = 0.f;
+                    continue;
+                }
+                float cmax = s[g][0];
+#pragma unroll
+                for (int i = 1; i < LG; ++i) cmax = fmaxf(cmax, s[g][i]);
+                const float mn = fmaxf(m[g], cmax);
+                const float alpha = fast_exp2(m[g] - mn);
+                m[g] = mn;
+                float psum = 0.f;
+#pragma unroll
+                for (int i = 0; i < LG; ++i) { s[g][i] = fast_exp2(s[g][i] - mn); psum += s[g][i]; }
+                l[g] = l[g] * alpha + psum;
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) o[g][e] *= alpha;
+            }
+#pragma unroll
+            for (int i = 0; i < LG; ++i) {
+                float vf[EPL];
+                unpack16<KVT>(vreg[i], vf);
+#pragma unroll
+                for (int g = 0; g < NQ; ++g) {
+                    if ((mask >> g) & 1u) {
+#pragma unroll
+                        for (int e = 0; e < EPL; ++e) o[g][e] = fmaf(s[g][i], vf[e], o[g][e]);
+                    }
+                }
+            }
+        }
+    }
+    // merge the 64/LPT token groups of the wave; the 4 waves are merged after the hand-over barrier
+#pragma unroll
+    for (int g = 0; g < NQ; ++g) {
+        if (QUANT) {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) o[g][e] -= 128.f * l[g];   // undo u = x + 128
+        }
+#pragma unroll
+        for (int step = LPT; step < 64; step <<= 1) {
+            float o2[EPL];
+            const float m2 = __shfl_xor(m[g], step), l2 = __shfl_xor(l[g], step);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) o2[e] = __shfl_xor(o[g][e], step);
+            merge_state(m[g], l[g], o[g], EPL, m2, l2, o2);
+        }
+        float* dst = comb + ((size_t)wave * NQ + g) * cstride;
+        if (grp == 0) {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) dst[sub * EPL + e] = o[g][e];
+            if (sub == 0) { dst[D] = m[g]; dst[D + 1] = l[g]; }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Streamer, MFMA form (2..16 q heads of a group share every K/V row; f16 / bf16 KV).
+//
+// Per 32-token tile of a page, one wave computes with v_mfma_f32_16x16x32:
+//   S^T[token][head] = K . Q^T     A = K rows straight from HBM (lane: token l&15, 16-byte slice l>>4 of each
+//                                  32-element k step), B = the q heads padded to 16 columns (loaded once per item);
+//   online softmax   in the accumulator layout: a lane holds 8 tokens (4 of each 16-token half) of head l&15;
+//                    the running maximum is shared by the 4 lanes of a head (two cross-lane exchanges per tile),
+//                    the running sum stays per lane until the end;
+//   O^T[d][head]    += V^T . P^T   B = P^T taken from the accumulator registers as they are (the k order of a step
+//                                  is free as long as both operands agree: k slot (l>>4, j) is token 4(l>>4)+j of the
+//                                  first half for j < 4 and of the second half for j >= 4), A = V^T read with
+//                                  ds_read_b64_tr_b16 from a row-major image of the tile in LDS (rows padded by
+//                                  32 B: the 8 rows a 32-lane half touches fall into 8 different bank groups).
+// V goes HBM -> VGPR -> LDS (wave-private area, so no workgroup barrier), K never touches LDS.  The next tile's
+// loads are issued before the current tile is computed.  P is split into a high and a low f16 / bf16 part (two
+// MFMAs, the matrix pipe is nearly idle anyway) so that its rounding stays far below the output tolerance.
+// ------------------------------------------------------------------------------------------------
+template <typename KVT, int LPT>
+__device__ __forceinline__ void stream_mfma(const AttnParams& p, const PageEntry* list, float* comb, char* vst,
+                                            int nU, int n2, long long row0, int R, int nq, float qscale,
+                                            int lane, int wave) {
+    constexpr bool BF16 = __is_same(KVT, __bf16);
+    constexpr int D = LPT * 8;
+    constexpr int KS = D / 32;                  // MFMA k steps of Q.K^T
+    constexpr int DT = D / 16;                  // 16-row tiles of O^T
+    constexpr int TPL = 64 / LPT;               // V rows per wave load
+    constexpr int VL = 32 / TPL;                // V wave loads per tile
+    constexpr int RS = D * 2 + 32;              // LDS row stride of the V image
+    constexpr bool PREFETCH = SPFA_MFMA_PREFETCH && LPT <= 16;   // two tiles of registers fit
+    constexpr float kNegBig = -1.0e30f;
+    typedef short short4v __attribute__((ext_vector_type(4)));
+    const int h = lane & 15, sg = lane >> 4;
+    const int cstride = D + 2;
+
+    uint4 qf[KS];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+        qf[kk] = make_uint4(0, 0, 0, 0);
+        if (h < R) qf[kk] = *(const uint4*)((const char*)p.q + ((row0 + h) * D + kk * 32 + sg * 8) * 2);
+    }
+    f32x4 o[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m = kNegBig, l = 0.f;
+
+    const int k_lane_off = h * (int)p.tok_stride + sg * 16;
+    const int v_lane_off = (lane / LPT) * (int)p.tok_stride + (lane % LPT) * 16;
+    char* v_wr = vst + (lane / LPT) * RS + (lane % LPT) * 16;
+    // transposed read: lane 4q+pp of a 16-lane group addresses row q, columns 4pp..4pp+3 of the 16-column block
+    const char* v_rd = vst + (4 * sg + (h >> 2)) * RS + (h & 3) * 8;
+
+    struct Tile { uint4 k[2][KS]; uint4 v[VL]; };
+    auto issue = [&](Tile& T, const __amdgpu_buffer_rsrc_t& rk, const __amdgpu_buffer_rsrc_t& rv, int t0) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk)
+                T.k[half][kk] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
+                    rk, k_lane_off + kk * 64, (t0 + 16 * half) * (int)p.tok_stride, SPFA_KV_AUX));
+#pragma unroll
+        for (int i = 0; i < VL; ++i)
+            T.v[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
+                rv, v_lane_off, (t0 + i * TPL) * (int)p.tok_stride, SPFA_KV_AUX));
+    };
+    auto compute = [&](const Tile& T, int t0, int valid, bool att) {
+        f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            if constexpr (BF16) {
+                sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, T.k[0][kk]),
+                                                             __builtin_bit_cast(bf16x8, qf[kk]), sa, 0, 0, 0);
+                sb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, T.k[1][kk]),
+                                                             __builtin_bit_cast(bf16x8, qf[kk]), sb, 0, 0, 0);
+            } else {
+                sa = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, T.k[0][kk]),
+                                                            __builtin_bit_cast(half8, qf[kk]), sa, 0, 0, 0);
+                sb = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, T.k[1][kk]),
+                                                            __builtin_bit_cast(half8, qf[kk]), sb, 0, 0, 0);
+            }
+        }
+        // V image of the tile: the previous tile's transposed reads were issued earlier by this same wave and
+        // LDS executes a wave's operations in order, so the area can be overwritten right away
+#pragma unroll
+        for (int i = 0; i < VL; ++i) *(uint4*)(v_wr + i * TPL * RS) = T.v[i];
+        float s[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ta = t0 + 4 * sg + r;
+            s[r] = (att && ta < valid) ? sa[r] * qscale : -INFINITY;
+            s[4 + r] = (att && ta + 16 < valid) ? sb[r] * qscale : -INFINITY;
+        }
+        float cmax = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
+        cmax = fmaxf(cmax, __shfl_xor(cmax, 16));
+        cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
+        const float mn = fmaxf(m, cmax);
+        const float alpha = fast_exp2(m - mn);
+        m = mn;
+        float pr[8], psum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { pr[j] = fast_exp2(s[j] - mn); psum += pr[j]; }
+        l = l * alpha + psum;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[dt] *= alpha;
+        asm volatile("" ::: "memory");   // the image is complete (in program order) before it is read back
+        __builtin_amdgcn_wave_barrier();
+        if constexpr (BF16) {
+            bf16x8 ph, pl;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                ph[j] = (__bf16)pr[j];
+                pl[j] = (__bf16)(pr[j] - (float)ph[j]);
+            }
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const short4v va = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) short4v*)(v_rd + dt * 32));
+                const short4v vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) short4v*)(v_rd + 16 * RS + dt * 32));
+                const uint4 vv = make_uint4(__builtin_bit_cast(uint2, va).x, __builtin_bit_cast(uint2, va).y,
+                                            __builtin_bit_cast(uint2, vb).x, __builtin_bit_cast(uint2, vb).y);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vv), ph, o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vv), pl, o[dt], 0, 0, 0);
+            }
+        } else {
+            half8 ph, pl;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                ph[j] = (_Float16)pr[j];
+                pl[j] = (_Float16)(pr[j] - (float)ph[j]);
+            }
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const short4v va = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) short4v*)(v_rd + dt * 32));
+                const short4v vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) short4v*)(v_rd + 16 * RS + dt * 32));
+                const uint4 vv = make_uint4(__builtin_bit_cast(uint2, va).x, __builtin_bit_cast(uint2, va).y,
+                                            __builtin_bit_cast(uint2, vb).x, __builtin_bit_cast(uint2, vb).y);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, vv), ph, o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, vv), pl, o[dt], 0, 0, 0);
+            }
+        }
+        asm volatile("" ::: "memory");
+    };
+
+    const int row_bytes = D * 2;
+    // page cursor of this wave: pages wave, wave + 4, ... of the list, 32-token tiles inside a page
+    int n = wave, t0 = 0, valid = 0;
+    bool att = false;
+    __amdgpu_buffer_rsrc_t rk, rv;
+    auto open_page = [&]() {
+        const int phys = __builtin_amdgcn_readfirstlane(list[n].phys);
+        valid = __builtin_amdgcn_readfirstlane((int)list[n].valid);
+        const unsigned mask = __builtin_amdgcn_readfirstlane((unsigned)list[n].mask);
+        att = (mask >> h) & 1u;
+        const long long off = (long long)phys * p.blk_stride + (long long)n2 * p.head_stride;
+        const int range = (valid - 1) * (int)p.tok_stride + row_bytes;   // dead rows of the page read as zeros
+        rk = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.kcache + off), 0, range, 0x00020000);
+        rv = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.vcache + off), 0, range, 0x00020000);
+    };
+    if (n < nU) {
+        open_page();
+        Tile cur;
+        issue(cur, rk, rv, 0);
+        while (true) {
+            const int c_t0 = t0, c_valid = valid;
+            const bool c_att = att;
+            t0 += 32;
+            if (t0 >= valid) { n += kStreamWaves; t0 = 0; if (n < nU) open_page(); }
+            const bool more = n < nU;
+            if constexpr (PREFETCH) {
+                Tile nxt;
+                if (more) issue(nxt, rk, rv, t0);
+                compute(cur, c_t0, c_valid, c_att);
+                if (!more) break;
+                cur = nxt;
+            } else {
+                compute(cur, c_t0, c_valid, c_att);
+                if (!more) break;
+                issue(cur, rk, rv, t0);
+            }
+        }
+    }
+    // this wave's state: the sum over its 4 lanes per head, O^T[d = 16 dt + 4 sg + r][head h]
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    if (h < R) {
+        float* dst = comb + ((size_t)wave * nq + h) * cstride;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+            *(f32x4*)(dst + dt * 16 + 4 * sg) = o[dt];
+        if (sg == 0) { dst[D] = m; dst[D + 1] = l; }
+    }
+}
+
+// NQ: q heads per pass of the VALU streamer (register arrays); the MFMA streamer takes p.rows_per_pass (<= 16).
+template <typename KVT, int NQ, int LPT, bool MFMA>
+__global__ __launch_bounds__(attn_threads(MFMA), (MFMA ? 2 : (NQ == 1 ? SPFA_MINWAVES : (NQ <= 4 ? SPFA_MINWAVES_N : 1))))
+void attn_kernel(const AttnParams p) {
+    constexpr int SW = sel_waves(MFMA);           // selector team size
+    constexpr int WAVES = kStreamWaves + SW;
+    constexpr bool QUANT = sizeof(KVT) == 1;
+    constexpr float kNegBig = -1.0e30f;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = lane_id(), wave = wave_id();
+    const bool selector = wave >= kStreamWaves;
+    const int sidx = wave - kStreamWaves;         // index inside the selector team (leader = 0)
+    const int D = p.D;
+    const int nq = MFMA ? p.rows_per_pass : NQ;   // row capacity of a pass (LDS areas are sized by it)
     const bool per_head = (p.mode == 0 && p.pos_rows == p.Hq && p.G > 1);   // every q head has its own list
     const int G_eff = per_head ? 1 : p.G;
-    const int n_pass = (G_eff + NQ - 1) / NQ;
+    const int n_pass = (G_eff + nq - 1) / nq;
     const int heads_per_b = per_head ? p.Hq : p.Hkv;
     const int total = p.B * heads_per_b * n_pass;
 
-    uint32_t* keys = (uint32_t*)(smem + p.off_keys);                              // [NQ][Cp]   (selector)
-    uint32_t* cbits = (uint32_t*)(smem + p.off_cbits);                            // [min(NQ,5)][Cp/32]
-    int* row_lens = (int*)(smem + p.off_pbits) - 8;                               // [8] list lengths of the first item
-    unsigned long long* pbits_all = (unsigned long long*)(smem + p.off_pbits);    // [NQ][n_pwords] (selector)
+    uint32_t* keys = (uint32_t*)(smem + p.off_keys);                              // [nq][Cp]   (selector)
+    uint32_t* cbits = (uint32_t*)(smem + p.off_cbits);                            // [min(nq,5)][Cp/32]
+    int* row_lens = (int*)(smem + p.off_pbits) - 16;                              // [16] list lengths of the first item
+    unsigned long long* pbits_all = (unsigned long long*)(smem + p.off_pbits);    // [nq][n_pwords] (selector)
     PageEntry* lists = (PageEntry*)(smem + p.off_list);                           // [2][max_entries]
-    float* combs = (float*)(smem + p.off_comb);                                   // [2][4][NQ][D+2]
-    float* qsts = (float*)(smem + p.off_qst);                                     // [2][NQ][D]
+    float* combs = (float*)(smem + p.off_comb);                                   // [2][4][nq][D+2]
+    float* qsts = (float*)(smem + p.off_qst);                                     // [2][nq][D]
     ItemHdr* hdrs = (ItemHdr*)(smem + p.off_hdr);                                 // [2]
+    int* team = (int*)(smem + p.off_hdr + 2 * sizeof(ItemHdr));                   // [0] sync counter, [1] item
+    int team_epoch = 0;
+    // Meeting point of the selector team (not of the workgroup): a counter in LDS.  Every team wave passes through
+    // the same sequence of calls, so the spin always ends; LDS operations of a wave execute in order, which makes
+    // everything it wrote before the increment visible to the wave that sees the count.
+    auto team_sync = [&]() {
+        wave_lds_sync();
+        if constexpr (SW > 1) {
+            team_epoch += SW;
+            if (lane == 0) atomicAdd(team, 1);
+            while (*(volatile int*)team < team_epoch) __builtin_amdgcn_s_sleep(1);
+            wave_lds_sync();
+        }
+    };
     const int n_pwords = (p.max_page + 63) >> 6;
     const int cstride = D + 2;
     const float qscale = p.scale * 1.4426950408889634f;   // scores in base-2 exponent units
@@ -644,8 +991,8 @@ __global__ __launch_bounds__(kAttnThreads, (NQ == 1 ? SPFA_MINWAVES : (NQ <= 4 ?
         const int pass = rest % n_pass;
         c.b = rest / n_pass;
         c.n2 = per_head ? hh / p.G : hh;
-        c.head0 = per_head ? hh : c.n2 * p.G + pass * NQ;
-        c.R = min(NQ, G_eff - pass * NQ);
+        c.head0 = per_head ? hh : c.n2 * p.G + pass * nq;
+        c.R = min(nq, G_eff - pass * nq);
         c.row0 = (long long)c.b * p.Hq + c.head0;
         return c;
     };
@@ -672,12 +1019,21 @@ __global__ __launch_bounds__(kAttnThreads, (NQ == 1 ? SPFA_MINWAVES : (NQ <= 4 ?
     auto build = [&](int slot, int item, int stage) {
         ItemHdr* hdr = hdrs + slot;
         PageEntry* list = lists + (size_t)slot * p.max_entries;
-        float* qst = qsts + (size_t)slot * NQ * D;
+        float* qst = qsts + (size_t)slot * nq * D;
         SPFA_STAMP(0);
-        if (item < 0) item = fetch_item(p.counters, xcd, total, (int)gridDim.x, lane);
+        if constexpr (SW > 1) {
+            if (sidx == 0) {
+                if (item < 0) item = fetch_item(p.counters, xcd, total, (int)gridDim.x, lane);
+                if (lane == 0) team[1] = item;
+            }
+            team_sync();
+            item = __builtin_amdgcn_readfirstlane(team[1]);
+        } else {
+            if (item < 0) item = fetch_item(p.counters, xcd, total, (int)gridDim.x, lane);
+        }
         SPFA_STAMP(1);
         if (item < 0) {
-            if (lane == 0) hdr->item = -1;
+            if (lane == 0 && sidx == 0) hdr->item = -1;
             return;
         }
         const ItemCtx ctx = decode(item);
@@ -688,23 +1044,31 @@ __global__ __launch_bounds__(kAttnThreads, (NQ == 1 ? SPFA_MINWAVES : (NQ <= 4 ?
         if (p.mode == 1) {
             const int seq = p.seq_len[b];
             const int page_len = page_len_of(b);
-            if (stage < 1) score_rows<1>(p.q, p.cent, p.q_dtype, row0, n2, R, D, p.C, p.Cp, keys);
-            wave_lds_sync();
+            if (stage < 1) score_rows<SW>(p.q, p.cent, p.q_dtype, row0, n2, R, D, p.C, p.Cp, keys, sidx);
+            team_sync();
             SPFA_STAMP(2);
+            if (stage < 2) {
+                for (int r = sidx; r < R; r += SW) {
+                    const int len = select_row(ctx, r, cbits + (size_t)sidx * (p.Cp >> 5), page_len);
+                    if (lane == 0) row_lens[r] = len;
+                }
+            }
+            team_sync();
+            if (sidx != 0) return;   // the leader finishes the item alone
             int len_max = 0;
-            for (int r = 0; r < R; ++r)
-                len_max = max(len_max, stage < 2 ? select_row(ctx, r, cbits, page_len) : row_lens[r]);
+            for (int r = 0; r < R; ++r) len_max = max(len_max, row_lens[r]);
             if (p.max_page_position_length && lane < kLenPad && len_max > 0)   // cent_select.cpp:124-152
                 atomicMax(p.max_page_position_length + (long long)b * kLenPad + lane,
                           (unsigned long long)len_max * (unsigned long long)p.block_size);
             SPFA_STAMP(4);
             // union of the pass's page lists, ascending, with a per-page head mask
             for (int w = 0; w < ((page_len + 63) >> 6); ++w) {
-                unsigned long long u = 0, mine = 0;
+                unsigned long long u = 0;
+                unsigned mine = 0;
                 for (int r = 0; r < R; ++r) {
                     const unsigned long long x = pbits_all[(size_t)r * n_pwords + w];
                     u |= x;
-                    mine |= ((x >> lane) & 1ull) << r;
+                    mine |= (unsigned)((x >> lane) & 1ull) << r;
                 }
                 if ((u >> lane) & 1ull) {
                     const int i = w * 64 + lane;
@@ -712,14 +1076,15 @@ __global__ __launch_bounds__(kAttnThreads, (NQ == 1 ? SPFA_MINWAVES : (NQ <= 4 ?
                     if (e < p.max_entries) {
                         PageEntry pe;
                         pe.phys = min(max(bt_row[i], 0), p.n_blocks - 1);
-                        pe.valid = min(p.block_size, seq - i * p.block_size);
-                        pe.mask = mine;
+                        pe.valid = (unsigned short)min(p.block_size, seq - i * p.block_size);
+                        pe.mask = (unsigned short)mine;
                         list[e] = pe;
                     }
                 }
                 nU += __popcll(u);
             }
         } else {
+            if (sidx != 0) return;
             // list = leading non-sentinel slots of the row, bounded by actual_seq_lengths
             // (…Us2.h:256-294; the kernel stops at the first 0x7fffffff, :308-311)
             const int prow = (p.pos_rows == p.Hq) ? head0 : n2;
@@ -738,8 +1103,8 @@ __global__ __launch_bounds__(kAttnThreads, (NQ == 1 ? SPFA_MINWAVES : (NQ <= 4 ?
                 if (lane < first && nU + lane < p.max_entries) {
                     PageEntry pe;
                     pe.phys = min(max(bt_row[pg], 0), p.n_blocks - 1);
-                    pe.valid = (int)min((long long)p.block_size, n_tok - (long long)j * p.block_size);
-                    pe.mask = (1ull << R) - 1ull;
+                    pe.valid = (unsigned short)min((long long)p.block_size, n_tok - (long long)j * p.block_size);
+                    pe.mask = (unsigned short)((1u << R) - 1u);
                     list[nU + lane] = pe;
                 }
                 nU += first;
@@ -747,8 +1112,8 @@ __global__ __launch_bounds__(kAttnThreads, (NQ == 1 ? SPFA_MINWAVES : (NQ <= 4 ?
             }
         }
         SPFA_STAMP(5);
-        // pre-scaled q rows (int8 KV: times the per-channel key scale, …Us2.h:2647)
-        for (int t = lane; t < NQ * D; t += 64) {
+        // pre-scaled q rows (int8 KV: times the per-channel key scale, …Us2.h:2647); the MFMA streamer reads q itself
+        for (int t = lane; !MFMA && t < nq * D; t += 64) {
             const int g = t / D, d = t - g * D;
             float v = 0.f;
             if (g < R) {
@@ -768,153 +1133,16 @@ __global__ __launch_bounds__(kAttnThreads, (NQ == 1 ? SPFA_MINWAVES : (NQ <= 4 ?
         }
     };
 
-    // ---------------- streamers: K/V pages of one item -> partial softmax states in LDS ----------------
-    auto stream = [&](int slot, int nU, int n2) {
-        const PageEntry* list = lists + (size_t)slot * p.max_entries;
-        const float* qst = qsts + (size_t)slot * NQ * D;
-        float* comb = combs + (size_t)slot * kStreamWaves * NQ * cstride;
-        float qf[NQ][EPL];
-        float qbias[NQ];   // int8: 128 * sum of this lane's q' (u = x + 128)
-#pragma unroll
-        for (int g = 0; g < NQ; ++g) {
-            qbias[g] = 0.f;
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) {
-                qf[g][e] = qst[g * D + sub * EPL + e];
-                qbias[g] += 128.f * qf[g][e];
-            }
-        }
-        float o[NQ][EPL], m[NQ], l[NQ];
-#pragma unroll
-        for (int g = 0; g < NQ; ++g) {
-            m[g] = kNegBig;
-            l[g] = 0.f;
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) o[g][e] = 0.f;
-        }
-        // Addressing: one buffer descriptor per page and head (uniform, SGPRs) + a per-lane byte offset
-        // that never changes (token group * token stride + 16-byte slice) + a scalar offset per wave
-        // load.  The descriptor's range ends at the page's last row of this head, so token slots past the
-        // block size read zeros instead of faulting.
-        const int lane_off = grp * (int)p.tok_stride + sub * 16;
-        const int page_range = (p.block_size - 1) * (int)p.tok_stride + D * (int)sizeof(KVT);
-        for (int n = wave; n < nU; n += kStreamWaves) {
-            const int phys = __builtin_amdgcn_readfirstlane(list[n].phys);
-            const int valid = __builtin_amdgcn_readfirstlane(list[n].valid);
-            const unsigned mask = __builtin_amdgcn_readfirstlane((unsigned)list[n].mask);
-            const long long off = (long long)phys * p.blk_stride + (long long)n2 * p.head_stride;
-            const __amdgpu_buffer_rsrc_t rk =
-                __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.kcache + off), 0, page_range, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rv =
-                __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.vcache + off), 0, page_range, 0x00020000);
-            for (int t0 = 0; t0 < valid; t0 += STEP) {
-                uint4 kreg[LG], vreg[LG];
-#if SPFA_BUFLOAD
-#pragma unroll
-                for (int i = 0; i < LG; ++i)
-                    kreg[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                            rk, lane_off, (t0 + i * TPL) * (int)p.tok_stride, SPFA_KV_AUX));
-#pragma unroll
-                for (int i = 0; i < LG; ++i)
-                    vreg[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                            rv, lane_off, (t0 + i * TPL) * (int)p.tok_stride, SPFA_KV_AUX));
-#else
-                const char* kp = (const char*)p.kcache + off;
-                const char* vp = (const char*)p.vcache + off;
-#pragma unroll
-                for (int i = 0; i < LG; ++i) {
-                    const int tok = min(t0 + i * TPL + grp, p.block_size - 1);
-                    kreg[i] = *(const uint4*)(kp + (unsigned)(tok * (int)p.tok_stride) + (unsigned)(sub * 16));
-                }
-#pragma unroll
-                for (int i = 0; i < LG; ++i) {
-                    const int tok = min(t0 + i * TPL + grp, p.block_size - 1);
-                    vreg[i] = *(const uint4*)(vp + (unsigned)(tok * (int)p.tok_stride) + (unsigned)(sub * 16));
-                }
-#endif
-                float s[NQ][LG];
-#pragma unroll
-                for (int i = 0; i < LG; ++i) {
-                    float kf[EPL];
-                    unpack16<KVT>(kreg[i], kf);
-                    const bool live = (t0 + i * TPL + grp) < valid;
-#pragma unroll
-                    for (int g = 0; g < NQ; ++g) {
-                        float acc = QUANT ? -qbias[g] : 0.f;
-#pragma unroll
-                        for (int e = 0; e < EPL; ++e) acc = fmaf(qf[g][e], kf[e], acc);
-                        acc = group_allsum<LPT>(acc);
-                        s[g][i] = live ? acc : -INFINITY;
-                    }
-                }
-#pragma unroll
-                for (int g = 0; g < NQ; ++g) {
-                    if (!((mask >> g) & 1u)) {   // wave-uniform: this head does not attend the page
-#pragma unroll
-                        for (int i = 0; i < LG; ++i) s[g][i] = 0.f;
-                        continue;
-                    }
-                    float cmax = s[g][0];
-#pragma unroll
-                    for (int i = 1; i < LG; ++i) cmax = fmaxf(cmax, s[g][i]);
-                    const float mn = fmaxf(m[g], cmax);
-                    const float alpha = fast_exp2(m[g] - mn);
-                    m[g] = mn;
-                    float psum = 0.f;
-#pragma unroll
-                    for (int i = 0; i < LG; ++i) { s[g][i] = fast_exp2(s[g][i] - mn); psum += s[g][i]; }
-                    l[g] = l[g] * alpha + psum;
-#pragma unroll
-                    for (int e = 0; e < EPL; ++e) o[g][e] *= alpha;
-                }
-#pragma unroll
-                for (int i = 0; i < LG; ++i) {
-                    float vf[EPL];
-                    unpack16<KVT>(vreg[i], vf);
-#pragma unroll
-                    for (int g = 0; g < NQ; ++g) {
-                        if ((mask >> g) & 1u) {
-#pragma unroll
-                            for (int e = 0; e < EPL; ++e) o[g][e] = fmaf(s[g][i], vf[e], o[g][e]);
-                        }
-                    }
-                }
-            }
-        }
-        // merge the 64/LPT token groups of the wave; the 4 waves are merged after the hand-over barrier
-#pragma unroll
-        for (int g = 0; g < NQ; ++g) {
-            if (QUANT) {
-#pragma unroll
-                for (int e = 0; e < EPL; ++e) o[g][e] -= 128.f * l[g];   // undo u = x + 128
-            }
-#pragma unroll
-            for (int step = LPT; step < 64; step <<= 1) {
-                float o2[EPL];
-                const float m2 = __shfl_xor(m[g], step), l2 = __shfl_xor(l[g], step);
-#pragma unroll
-                for (int e = 0; e < EPL; ++e) o2[e] = __shfl_xor(o[g][e], step);
-                merge_state(m[g], l[g], o[g], EPL, m2, l2, o2);
-            }
-            float* dst = comb + ((size_t)wave * NQ + g) * cstride;
-            if (grp == 0) {
-#pragma unroll
-                for (int e = 0; e < EPL; ++e) dst[sub * EPL + e] = o[g][e];
-                if (sub == 0) { dst[D] = m[g]; dst[D + 1] = l[g]; }
-            }
-        }
-    };
-
     // ---------------- merge the 4 streamer states of a finished item and store its output rows ----------------
     auto finalize = [&](int slot, int row0, int R, int n2) {
-        const float* comb = combs + (size_t)slot * kStreamWaves * NQ * cstride;
+        const float* comb = combs + (size_t)slot * kStreamWaves * nq * cstride;
         for (int t = threadIdx.x; t < R * D; t += kStreamWaves * 64) {
             const int g = t / D, d = t - g * D;
             float mt = kNegBig;
-            for (int w = 0; w < kStreamWaves; ++w) mt = fmaxf(mt, comb[((size_t)w * NQ + g) * cstride + D]);
+            for (int w = 0; w < kStreamWaves; ++w) mt = fmaxf(mt, comb[((size_t)w * nq + g) * cstride + D]);
             float acc = 0.f, lt = 0.f;
             for (int w = 0; w < kStreamWaves; ++w) {
-                const float* src = comb + ((size_t)w * NQ + g) * cstride;
+                const float* src = comb + ((size_t)w * nq + g) * cstride;
                 const float c = fast_exp2(src[D] - mt);
                 acc += src[d] * c;
                 lt += src[D + 1] * c;
@@ -936,26 +1164,32 @@ __global__ __launch_bounds__(kAttnThreads, (NQ == 1 ? SPFA_MINWAVES : (NQ <= 4 ?
     // First item: static (no counter round trip) and scored by all five waves together, because nothing can
     // be streamed before the first page list exists.
     int slot = 0;
+    if (threadIdx.x == 0) team[0] = 0;
+    __syncthreads();
+    if (wave == 0) SPFA_STAMP(11);
     {
         const int item0 = (int)blockIdx.x;   // grid <= total
         int stage0 = 1;
         if (p.mode == 1) {
             const ItemCtx c0 = decode(item0);
-            score_rows<kStreamWaves + 1>(p.q, p.cent, p.q_dtype, c0.row0, c0.n2, c0.R, D, p.C, p.Cp, keys);
+            score_rows<WAVES>(p.q, p.cent, p.q_dtype, c0.row0, c0.n2, c0.R, D, p.C, p.Cp, keys, wave);
             __syncthreads();
-            if (NQ > 1 && c0.R > 1) {   // one wave per row instead of the selector walking all of them
+            if (wave == 0) SPFA_STAMP(12);
+            if (c0.R > 1) {   // one wave per row instead of the selector walking all of them
                 const int page_len = page_len_of(c0.b);
-                for (int r = wave; r < c0.R; r += kStreamWaves + 1) {
+                for (int r = wave; r < c0.R; r += WAVES) {
                     const int len = select_row(c0, r, cbits + (size_t)wave * (p.Cp >> 5), page_len);
                     if (lane == 0) row_lens[r] = len;
                 }
                 __syncthreads();
+                if (wave == 0) SPFA_STAMP(13);
                 stage0 = 2;
             }
         }
         if (selector) build(0, item0, stage0);
     }
     __syncthreads();
+    if (wave == 0) SPFA_STAMP(14);
 #ifdef SPFA_STAMPS
     stamp_item = 1;
 #endif
@@ -976,7 +1210,14 @@ __global__ __launch_bounds__(kAttnThreads, (NQ == 1 ? SPFA_MINWAVES : (NQ <= 4 ?
         if (selector) build(slot ^ 1, -1, 0);
         else {
             if (wave == 0) SPFA_STAMP(8);
-            stream(slot, nU, n2);
+            if constexpr (MFMA)
+                stream_mfma<KVT, LPT>(p, lists + (size_t)slot * p.max_entries,
+                                      combs + (size_t)slot * kStreamWaves * nq * cstride,
+                                      smem + p.off_vst + (size_t)wave * (32 * (LPT * 16 + 32)), nU, n2, row0, R, nq,
+                                      qscale, lane, wave);
+            else
+                stream_valu<KVT, NQ, LPT>(p, lists + (size_t)slot * p.max_entries, qsts + (size_t)slot * nq * D,
+                                          combs + (size_t)slot * kStreamWaves * nq * cstride, nU, n2, lane, wave);
             if (wave == 0) SPFA_STAMP(9);
         }
         __syncthreads();
@@ -989,16 +1230,14 @@ __global__ __launch_bounds__(kAttnThreads, (NQ == 1 ? SPFA_MINWAVES : (NQ <= 4 ?
     }
 }
 
-template <typename KVT, int NQ, int LPT>
+template <typename KVT, int NQ, int LPT, bool MFMA>
 hipError_t launch_attn_one(const AttnParams& p, hipStream_t s) {
-    auto kern = attn_kernel<KVT, NQ, LPT>;
-    static int blocks_per_cu = 0, n_cu = 0;   // per (kernel, process): residency of the persistent grid
-    if (blocks_per_cu == 0 || p.lds_bytes > 48 * 1024) {
-        if (p.lds_bytes > 48 * 1024) {
-            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               (int)p.lds_bytes);
-            if (e != hipSuccess) return e;
-        }
+    auto kern = attn_kernel<KVT, NQ, LPT, MFMA>;
+    static int n_cu = 0;
+    if (p.lds_bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)p.lds_bytes);
+        if (e != hipSuccess) return e;
     }
     int dev = 0, occ = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -1007,70 +1246,87 @@ hipError_t launch_attn_one(const AttnParams& p, hipStream_t s) {
         e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
         if (e != hipSuccess) return e;
     }
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, kAttnThreads, p.lds_bytes);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, attn_threads(MFMA), p.lds_bytes);
     if (e != hipSuccess) return e;
-    blocks_per_cu = occ < 1 ? 1 : occ;
+    int blocks_per_cu = occ < 1 ? 1 : occ;   // residency of the persistent grid
     // 8 streamer waves per CU already saturate HBM; a third workgroup only deepens the memory queues
     if (blocks_per_cu > SPFA_WGS_PER_CU) blocks_per_cu = SPFA_WGS_PER_CU;
     const bool per_head = (p.mode == 0 && p.pos_rows == p.Hq && p.G > 1);
     const int g_eff = per_head ? 1 : p.G;
-    const long long total = (long long)p.B * (per_head ? p.Hq : p.Hkv) * ((g_eff + NQ - 1) / NQ);
+    const int nq = MFMA ? p.rows_per_pass : NQ;
+    const long long total = (long long)p.B * (per_head ? p.Hq : p.Hkv) * ((g_eff + nq - 1) / nq);
     if (total == 0) return hipSuccess;
     const long long cap = (long long)n_cu * blocks_per_cu;
     const dim3 grid((unsigned)(total < cap ? total : cap));
     static bool said = false;
     if (!said && getenv("SPFA_DEBUG")) {
         said = true;
-        fprintf(stderr, "[spfa] attn grid=%u blocks/CU=%d CUs=%d lds=%zu items=%lld\n", grid.x, blocks_per_cu, n_cu, p.lds_bytes, total);
+        fprintf(stderr, "[spfa] attn grid=%u blocks/CU=%d CUs=%d lds=%zu items=%lld mfma=%d\n", grid.x, blocks_per_cu, n_cu,
+                p.lds_bytes, total, (int)MFMA);
     }
-    hipLaunchKernelGGL(kern, grid, dim3(kAttnThreads), p.lds_bytes, s, p);
+    hipLaunchKernelGGL(kern, grid, dim3(attn_threads(MFMA)), p.lds_bytes, s, p);
     return hipGetLastError();
 }
 
+// One q head per pass (MHA, or a group whose heads bring their own lists), or int8 KV: VALU streamer.
 template <typename KVT, int NQ>
-hipError_t launch_attn_lpt(const AttnParams& p, int lpt, hipStream_t s) {
+hipError_t launch_attn_valu(const AttnParams& p, int lpt, hipStream_t s) {
     switch (lpt) {
 #ifndef SPFA_EXPLORE
-        case 4: return launch_attn_one<KVT, NQ, 4>(p, s);
-        case 8: return launch_attn_one<KVT, NQ, 8>(p, s);
-        case 32: return launch_attn_one<KVT, NQ, 32>(p, s);
+        case 4: return launch_attn_one<KVT, NQ, 4, false>(p, s);
+        case 8: return launch_attn_one<KVT, NQ, 8, false>(p, s);
+        case 32: return launch_attn_one<KVT, NQ, 32, false>(p, s);
 #endif
-        case 16: return launch_attn_one<KVT, NQ, 16>(p, s);
+        case 16: return launch_attn_one<KVT, NQ, 16, false>(p, s);
     }
     return hipErrorInvalidValue;
 }
 
+// Several q heads share the K/V rows (f16 / bf16): MFMA streamer.
 template <typename KVT>
-hipError_t launch_attn_nq(const AttnParams& p, int nq, int lpt, hipStream_t s) {
-    switch (nq) {
-#ifdef SPFA_EXPLORE
-        case SPFA_EXPLORE_NQ: return launch_attn_lpt<KVT, SPFA_EXPLORE_NQ>(p, lpt, s);
-#else
-        case 1: return launch_attn_lpt<KVT, 1>(p, lpt, s);
-        case 4: return launch_attn_lpt<KVT, 4>(p, lpt, s);
-        case 8: return launch_attn_lpt<KVT, 8>(p, lpt, s);
+hipError_t launch_attn_mfma(const AttnParams& p, int lpt, hipStream_t s) {
+    switch (lpt) {
+#ifndef SPFA_EXPLORE
+        case 4: return launch_attn_one<KVT, 16, 4, true>(p, s);
+        case 8: return launch_attn_one<KVT, 16, 8, true>(p, s);
+        case 32: return launch_attn_one<KVT, 16, 32, true>(p, s);
 #endif
+        case 16: return launch_attn_one<KVT, 16, 16, true>(p, s);
     }
     return hipErrorInvalidValue;
 }
 
 }  // namespace
 
+bool attention_uses_mfma(int rows_per_pass, int kv_dtype) { return rows_per_pass > 1 && kv_dtype != kI8; }
+
 int attention_rows_per_pass(int G, int kv_dtype) {
     if (G <= 1) return 1;
-    return (G <= 4 || kv_dtype == kI8) ? 4 : 8;   // int8 rows cost 16 accumulators each
+    if (kv_dtype == kI8) return 4;   // VALU streamer: int8 rows cost 16 accumulators each
+    return G < 16 ? G : 16;          // MFMA streamer: up to 16 columns
 }
 
 hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
-    const bool per_head = (p.mode == 0 && p.pos_rows == p.Hq && p.G > 1);
-    const int nq = per_head ? 1 : p.rows_per_pass;
+    const int nq = p.rows_per_pass;
     const int esize = (p.kv_dtype == kI8) ? 1 : 2;
     const int lpt = p.D * esize / 16;
+    if (attention_uses_mfma(nq, p.kv_dtype)) {
+        if (nq > 16) return hipErrorInvalidValue;
+#ifdef SPFA_EXPLORE
+        if (p.kv_dtype == kF16) return launch_attn_mfma<_Float16>(p, lpt, s);
+        return hipErrorInvalidValue;
+#else
+        return p.kv_dtype == kBF16 ? launch_attn_mfma<__bf16>(p, lpt, s) : launch_attn_mfma<_Float16>(p, lpt, s);
+#endif
+    }
     switch (p.kv_dtype) {
-        case kF16: return launch_attn_nq<_Float16>(p, nq, lpt, s);
+        case kF16: if (nq == 1) return launch_attn_valu<_Float16, 1>(p, lpt, s); break;
 #ifndef SPFA_EXPLORE
-        case kBF16: return launch_attn_nq<__bf16>(p, nq, lpt, s);
-        case kI8: return launch_attn_nq<int8_t>(p, nq, lpt, s);
+        case kBF16: if (nq == 1) return launch_attn_valu<__bf16, 1>(p, lpt, s); break;
+        case kI8:
+            if (nq == 1) return launch_attn_valu<int8_t, 1>(p, lpt, s);
+            if (nq == 4) return launch_attn_valu<int8_t, 4>(p, lpt, s);
+            break;
 #endif
     }
     return hipErrorInvalidValue;

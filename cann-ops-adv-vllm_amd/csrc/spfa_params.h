@@ -84,7 +84,7 @@ struct AttnParams {
     unsigned* counters;            // 8 work counters (workspace), zeroed before every launch
     unsigned long long* debug;     // diagnostic builds only: [grid][16 items][16 stamps], else null
     // LDS carve (bytes from the dynamic base)
-    int off_keys, off_cbits, off_pbits, off_list, off_comb, off_qst, off_hdr;
+    int off_keys, off_cbits, off_pbits, off_list, off_comb, off_qst, off_hdr, off_vst;
     size_t lds_bytes;
 };
 
@@ -92,7 +92,9 @@ hipError_t launch_compute_cent(const CentParams& p, hipStream_t s);
 hipError_t launch_cent_select(const CentParams& p, hipStream_t s);
 hipError_t launch_select_position(const SelectParams& p, hipStream_t s);
 hipError_t launch_attention(const AttnParams& p, hipStream_t s);
-// Number of q heads of a group an attention pass can hold in registers for this G.
+// Number of q heads of a group one pass over the K/V pages serves, and whether that pass runs on the MFMA streamer
+// (which stages V tiles in LDS: 4 waves x 32 rows x (2 D + 32) bytes at off_vst).
 int attention_rows_per_pass(int G, int kv_dtype);
+bool attention_uses_mfma(int rows_per_pass, int kv_dtype);
 
 }  // namespace spfa

@@ -85,7 +85,11 @@ def _random_lists(rng, B, rows, max_page, P, lo, hi):
     ("bf16", "BNSD", 16, 2, "kv", 64, 32, "uniform"),
     ("f16", "BSH", 4, 4, "kv", 64, 128, "device"),
     ("f16", "BSH", 4, 1, "kv", 256, 64, "none"),
-    ("f16", "BSH", 32, 2, "kv", 128, 128, "ragged"),     # G = 16: two passes of 8 heads
+    ("f16", "BSH", 32, 2, "kv", 128, 128, "ragged"),     # G = 16: one pass of 16 heads
+    ("f16", "BSH", 6, 2, "kv", 128, 48, "ragged"),       # G = 3, pages of one and a half 32-token tiles
+    ("bf16", "BSH", 32, 1, "kv", 128, 128, "device"),    # G = 32: two passes of 16 heads
+    ("f16", "BNSD", 4, 2, "kv", 32, 16, "ragged"),       # G = 2, D = 32
+    ("bf16", "BSH", 10, 2, "kv", 256, 32, "none"),       # G = 5, D = 256
 ])
 def test_attention_vs_oracle(H, dtype, layout, Hq, Hkv, rows, D, bs, seq_mode):
     rng = datagen.rng_for(1234 + Hq * 7 + D)
@@ -209,6 +213,36 @@ def test_fusion_page_multiple_equals_separate(H):
     assert torch.equal(spos, pos)
     sep = H.call_attention(qd, kd, vd, td, spos, smax[:, 0].contiguous(), Hq, Hkv, 1.0, bs, out_dtype=torch.float32)
     assert float(parity.rel_err(H.f32(out), H.f32(sep)).max()) <= TOL
+
+
+@pytest.mark.parametrize("Hq,Hkv,kvdt", [(8, 8, "f16"), (8, 2, "f16"), (8, 2, "bf16"), (16, 2, "f16")])
+def test_dead_tokens_of_the_last_page_are_never_used(H, Hq, Hkv, kvdt):
+    """Token slots past total_seq_len hold NaN bit patterns (a cache page is not cleared before reuse): the result
+    must not depend on them."""
+    D, C, topk, bs, pages = 128, 128, 128, 128, 8    # k = C: every page of a sequence is selected
+    seq_lens = [3 * bs + 5, 7 * bs + 127, 1]
+    B = len(seq_lens)
+    q, l1 = datagen.cent_case(91, B, Hq, Hkv, D, C, grid=True)
+    ids, table, seq = datagen.page_case(91, Hkv, C, B * pages, B, pages, seq_lens, aliasing=False)
+    k, v = datagen.kv_case(91, B * pages, bs, Hkv, D, "BSH", dist="randn")
+    tdt = torch.float16 if kvdt == "f16" else torch.bfloat16
+    if kvdt == "bf16":
+        k, v = (ref.round_to_bf16(x.astype(np.float32)) for x in (k, v))
+    scale = D ** -0.5
+    want, wpos, wlen, wmax = ref.sparse_paged_fusion_attention(q, k, v, table, l1, ids, seq, Hq, Hkv, scale, bs, topk, 256)
+    assert [int(x) for x in wlen[:, 0, 0]] == [4, 8, 1]
+    kd, vd = H.dev(k, tdt), H.dev(v, tdt)
+    for b, n in enumerate(seq_lens):      # poison every token slot at or past the sequence end
+        for j in range(pages):
+            first_dead = min(max(n - j * bs, 0), bs)
+            kd[int(table[b, j]), first_dead:] = float("nan")
+            vd[int(table[b, j]), first_dead:] = float("nan")
+    qd, l1d, td, idsd, seqd = H.dev(q, tdt), H.dev(l1, tdt), H.dev(table), H.dev(ids), H.dev(seq)
+    out, pos, plen, pmax = H.call_fusion(qd, kd, vd, td, l1d, idsd, seqd, Hq, Hkv, scale, bs, topk,
+                                         out_dtype=torch.float32)
+    assert np.array_equal(pos.cpu().numpy(), wpos)
+    assert bool(torch.isfinite(out).all())
+    assert float(parity.rel_err(H.f32(out), want).max()) <= TOL
 
 
 @pytest.mark.parametrize("Hq,Hkv,with_offset", [(8, 2, True), (4, 4, False), (8, 1, True)])

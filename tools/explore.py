@@ -59,6 +59,24 @@ def main():
         print(f"attention BSH    {t_at*1e3:8.1f} us  {gbytes/t_at/1e6:8.1f} GB/s")
     except RuntimeError as ex:   # exploration builds hold one instantiation only
         print("attention BSH    n/a:", str(ex)[:60])
+    G = Hq // Hkv
+    if G > 1:
+        # the group's union list as a shared [B,Hkv,P] block_position: the streaming floor of the fused op
+        Pn = 256 * G
+        valid = torch.arange(256, device=dev)[None, None, :] < plen[:, :, :1]
+        hit = torch.zeros((B, Hkv, wl["page_len"] + 1), dtype=torch.bool, device=dev)
+        idx = torch.where(valid, pos.long(), torch.full_like(pos, wl["page_len"]).long()).reshape(B, Hkv, G * 256)
+        hit.scatter_(2, idx, True)
+        hit = hit[:, :, :wl["page_len"]]
+        order = torch.argsort((~hit).to(torch.int8), dim=2, stable=True)[:, :, :Pn].to(torch.int32)
+        n = hit.sum(dim=2, keepdim=True)
+        upos = torch.where(torch.arange(order.shape[2], device=dev)[None, None, :] < n, order,
+                           torch.full_like(order, 0x7fffffff)).contiguous()
+        act_u = (n.max(dim=1).values.reshape(B).long() * bs).contiguous()
+        t_u = timeit(lambda: custom_ops.sparse_paged_attention(wl["q"], wl["key"], wl["val"], e, e, act_u, e, e, e, e, e,
+                                                               asc, aof, wl["table"], ei, upos, Hq, D ** -0.5, "BNSD",
+                                                               Hkv, bs, 1))
+        print(f"attention union  {t_u*1e3:8.1f} us  {gbytes/t_u/1e6:8.1f} GB/s")
     if os.environ.get("EXPLORE_BNSD", "1") == "1":
         kb = wl["key"].permute(0, 2, 1, 3).contiguous()
         vb = wl["val"].permute(0, 2, 1, 3).contiguous()

@@ -63,6 +63,12 @@ for it in range(5):
         print(f"item#{it}: n={int(ms.sum())} stream={np.median(row[ms, 9] - row[ms, 8]):.0f} "
               f"wait_after_stream={np.median(row[ms, 10] - row[ms, 9]):.0f} first_start={np.median(row[ms, 8]) - d_attn[d_attn > 0].min():.0f}")
 d = report("fused", plan.run)
+row = d[:, 0, :]
+ok = row[:, 11] > 0
+t_first = row[ok, 11].min()
+print(f"prologue: kernel-start spread={np.median(row[ok, 11] - t_first):.0f} score={np.median(row[ok, 12] - row[ok, 11]):.0f} "
+      f"rows={np.median((row[ok, 13] - row[ok, 12])[row[ok, 13] > 0]) if (row[ok, 13] > 0).any() else 0:.0f} "
+      f"end-start={np.median(row[ok, 14] - row[ok, 11]):.0f} last_end={(d[:, :, 9].max() - t_first)}")
 names = {(0, 1): "fetch", (1, 2): "score", (2, 3): "topk", (3, 4): "select", (4, 5): "union", (5, 6): "qstage"}
 for it in range(5):
     row = d[:, it, :]
