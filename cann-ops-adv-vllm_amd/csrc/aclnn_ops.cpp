@@ -38,6 +38,9 @@ struct aclOpExecutor {
     spfa::SelectParams sel{};
     spfa::AttnParams attn{};
     std::vector<long long> act_seq;   // host copy of actualSeqLengths, expanded to B values
+    // workspace layout of the two attention ops: [work counters | split arrival counters] (zeroed per launch),
+    // split states, per-batch actualSeqLengths
+    uint64_t ws_zero_bytes = 0, ws_parts_off = 0, ws_lengths_off = 0;
     uint64_t ws_bytes = 0;
 };
 
@@ -572,6 +575,38 @@ static aclnnStatus plan_lds(spfa::AttnParams& p) {
     return ACLNN_SUCCESS;
 }
 
+// Small batches leave most of the chip idle with one workgroup per item: deal each item's page list to several
+// workgroups (the kernel merges their states in the same launch).  Decided here because the workspace holds the
+// states; needs the CU count of the current device (no device: no split).
+static void plan_workspace(aclOpExecutor* e) {
+    spfa::AttnParams& p = e->attn;
+    auto up256 = [](uint64_t x) { return (x + 255) & ~255ull; };
+    const bool per_head = (p.mode == 0 && p.pos_rows == p.Hq && p.G > 1);
+    const int g_eff = per_head ? 1 : p.G;
+    const long long items = (long long)p.B * (per_head ? p.Hq : p.Hkv) * ((g_eff + p.rows_per_pass - 1) / p.rows_per_pass);
+    p.n_split = 1;
+    const int n_cu = spfa::device_cu_count();
+    if (items > 0 && items * 2 <= n_cu) {
+        long long ns = n_cu / items;
+        if (ns > 16) ns = 16;
+        if (ns > p.max_entries) ns = p.max_entries;   // at least one page per share
+        if (ns > 1) p.n_split = (int)ns;
+    }
+    e->ws_zero_bytes = kCounterBytes + (p.n_split > 1 ? up256((uint64_t)items * 4) : 0);
+    e->ws_parts_off = e->ws_zero_bytes;
+    const uint64_t parts = p.n_split > 1 ? up256((uint64_t)items * p.n_split * p.rows_per_pass * (p.D + 2) * 4) : 0;
+    e->ws_lengths_off = e->ws_parts_off + parts;
+    e->ws_bytes = e->ws_lengths_off + (e->act_seq.empty() ? 0 : up256((uint64_t)p.B * 8));
+}
+
+// Bind the planned workspace layout to the caller's buffer and enqueue the zeroing of its counters.
+static hipError_t bind_workspace(const aclOpExecutor* e, spfa::AttnParams& p, void* workspace, hipStream_t stream) {
+    p.counters = (unsigned*)workspace;
+    p.split_done = (unsigned*)((char*)workspace + kCounterBytes);
+    p.split_partials = (float*)((char*)workspace + e->ws_parts_off);
+    return hipMemsetAsync(workspace, 0, e->ws_zero_bytes, stream);
+}
+
 #define REJECT_PRESENT(t, name) \
     REQUIRE(absent(t), "%s is not supported on the sparse paged path (must be empty)", name)
 
@@ -631,7 +666,7 @@ aclnnStatus aclnnSparsePagedAttentionGetWorkspaceSize(
     }
     st = plan_lds(p);
     if (st != ACLNN_SUCCESS) return bail(st);
-    e->ws_bytes = kCounterBytes + (e->act_seq.empty() ? 0 : (((uint64_t)p.B * 8 + 255) & ~255ull));
+    plan_workspace(e);
     *workspaceSize = e->ws_bytes;
     *executor = e;
     return ACLNN_SUCCESS;
@@ -647,10 +682,9 @@ aclnnStatus aclnnSparsePagedAttention(void* workspace, uint64_t workspaceSize, a
         if (!executor->repeatable) delete executor;
         return fail(ACLNN_ERR_PARAM_INVALID, "workspace of %llu bytes required", need);
     }
-    p.counters = (unsigned*)workspace;
-    hipError_t err = hipMemsetAsync(workspace, 0, kCounterBytes, (hipStream_t)stream);
+    hipError_t err = bind_workspace(executor, p, workspace, (hipStream_t)stream);
     if (err == hipSuccess && !executor->act_seq.empty()) {
-        void* lengths = (char*)workspace + kCounterBytes;
+        void* lengths = (char*)workspace + executor->ws_lengths_off;
         // Per-batch lengths travel through the workspace.  A one-shot executor dies when this call
         // returns, so its host copy is handed to the stream and freed there after the copy ran.
         const long long* src = executor->act_seq.data();
@@ -742,7 +776,7 @@ aclnnStatus aclnnSparsePagedFusionAttentionGetWorkspaceSize(
     p.max_entries = max_page;   // the union of a group's lists never exceeds the logical page count
     st = plan_lds(p);
     if (st != ACLNN_SUCCESS) return bail(st);
-    e->ws_bytes = kCounterBytes;
+    plan_workspace(e);
     *workspaceSize = e->ws_bytes;
     *executor = e;
     return ACLNN_SUCCESS;
@@ -758,8 +792,7 @@ aclnnStatus aclnnSparsePagedFusionAttention(void* workspace, uint64_t workspaceS
         if (!executor->repeatable) delete executor;
         return fail(ACLNN_ERR_PARAM_INVALID, "workspace of %llu bytes required", need);
     }
-    p.counters = (unsigned*)workspace;
-    hipError_t err = hipMemsetAsync(workspace, 0, kCounterBytes, (hipStream_t)stream);
+    hipError_t err = bind_workspace(executor, p, workspace, (hipStream_t)stream);
     if (err == hipSuccess && p.max_page_position_length && p.B > 0)   // accumulated with atomicMax
         err = hipMemsetAsync(p.max_page_position_length, 0, (size_t)p.B * spfa::kLenPad * 8, (hipStream_t)stream);
     if (err == hipSuccess) err = spfa::launch_attention(p, (hipStream_t)stream);

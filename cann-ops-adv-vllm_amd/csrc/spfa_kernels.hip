@@ -489,11 +489,12 @@ struct PageEntry {            // 8 bytes in LDS
 };
 struct ItemHdr {              // 32 bytes in LDS
     int item;                 // < 0: no more work
-    int nU;                   // page list length
+    int nU;                   // pages to stream: list[lo .. lo + nU)
     int b, n2;
     int row0;                 // first output row (b * Hq + head) of the pass
     int R;                    // q heads in the pass
-    int pad[2];
+    int lo;                   // first list entry of this workgroup's share (page-list split, else 0)
+    int pad;
 };
 
 template <typename KVT> struct KvTraits;
@@ -947,7 +948,11 @@ void attn_kernel(const AttnParams p) {
     const int G_eff = per_head ? 1 : p.G;
     const int n_pass = (G_eff + nq - 1) / nq;
     const int heads_per_b = per_head ? p.Hq : p.Hkv;
-    const int total = p.B * heads_per_b * n_pass;
+    // Page-list split (small batches): every item is dealt to NS workgroups, each repeats the (deterministic)
+    // selection, streams one NS-th of the list and leaves an un-normalised state in global memory; the last
+    // of them to arrive merges the NS states.  Then there is exactly one unit per workgroup.
+    const int NS = p.n_split;
+    const int total = p.B * heads_per_b * n_pass * NS;
 
     uint32_t* keys = (uint32_t*)(smem + p.off_keys);                              // [nq][Cp]   (selector)
     uint32_t* cbits = (uint32_t*)(smem + p.off_cbits);                            // [min(nq,5)][Cp/32]
@@ -982,10 +987,12 @@ void attn_kernel(const AttnParams p) {
 #endif
 
     // ---------------- selector: everything that precedes the page stream of one item ----------------
-    struct ItemCtx { int b, n2, head0, R; long long row0; };
-    auto decode = [&](int item) {
-        // item -> (batch, head, pass); item % 8 picks the XCD class, so keep the kv head in the low part
+    struct ItemCtx { int b, n2, head0, R, split; long long row0; };
+    auto decode = [&](int unit) {
+        // unit -> (batch, head, pass, split); unit % 8 picks the XCD class, so keep the kv head in the low part
         ItemCtx c;
+        c.split = unit % NS;
+        const int item = unit / NS;
         const int hh = item % heads_per_b;
         const int rest = item / heads_per_b;
         const int pass = rest % n_pass;
@@ -1005,9 +1012,10 @@ void attn_kernel(const AttnParams p) {
         const int len = select_pages(cb, p.C, p.block_table + (long long)ctx.b * p.max_page,
                                      p.block_ids + (long long)ctx.n2 * p.kv_page_len, p.kv_page_len, page_len, p.P,
                                      p.sink_recent, p.cap_pages,
-                                     p.page_position ? p.page_position + row * p.P : nullptr,
+                                     (p.page_position && ctx.split == 0) ? p.page_position + row * p.P : nullptr,
                                      pbits_all + (size_t)r * n_pwords, n_pwords, lane);
-        if (p.page_position_length && lane < kLenPad) p.page_position_length[row * kLenPad + lane] = len;
+        if (p.page_position_length && ctx.split == 0 && lane < kLenPad)
+            p.page_position_length[row * kLenPad + lane] = len;
         wave_lds_sync();
         return len;
     };
@@ -1057,7 +1065,7 @@ void attn_kernel(const AttnParams p) {
             if (sidx != 0) return;   // the leader finishes the item alone
             int len_max = 0;
             for (int r = 0; r < R; ++r) len_max = max(len_max, row_lens[r]);
-            if (p.max_page_position_length && lane < kLenPad && len_max > 0)   // cent_select.cpp:124-152
+            if (p.max_page_position_length && ctx.split == 0 && lane < kLenPad && len_max > 0)   // cent_select.cpp:124-152
                 atomicMax(p.max_page_position_length + (long long)b * kLenPad + lane,
                           (unsigned long long)len_max * (unsigned long long)p.block_size);
             SPFA_STAMP(4);
@@ -1124,8 +1132,12 @@ void attn_kernel(const AttnParams p) {
         }
         SPFA_STAMP(6);
         if (lane == 0) {
+            nU = min(nU, p.max_entries);
+            const int share = (nU + NS - 1) / NS;
+            const int lo = min(nU, ctx.split * share);
             hdr->item = item;
-            hdr->nU = min(nU, p.max_entries);
+            hdr->nU = min(nU, lo + share) - lo;
+            hdr->lo = lo;
             hdr->b = b;
             hdr->n2 = n2;
             hdr->row0 = (int)row0;
@@ -1134,6 +1146,18 @@ void attn_kernel(const AttnParams p) {
     };
 
     // ---------------- merge the 4 streamer states of a finished item and store its output rows ----------------
+    auto store_out = [&](long long row, int d, int n2, float acc, float lt) {
+        float r = lt > 0.f ? acc / lt : 0.f;
+        if (QUANT && lt > 0.f) {   // (P.V / l + offset_v) * scale_v, …Us2.h:4160-4174
+            const long long pi = (long long)p.Hkv * D + (long long)n2 * D + d;   // value params follow the key params
+            if (p.antiq_offset) r += load_qk_elem(p.antiq_offset, p.q_dtype, pi);
+            r *= load_qk_elem(p.antiq_scale, p.q_dtype, pi);
+        }
+        const long long oi = row * D + d;
+        if (p.out_dtype == kF32) ((float*)p.out)[oi] = r;
+        else if (p.out_dtype == kBF16) ((__bf16*)p.out)[oi] = (__bf16)r;   // round to nearest even (…Us2.h:3476-3477)
+        else ((_Float16*)p.out)[oi] = (_Float16)r;
+    };
     auto finalize = [&](int slot, int row0, int R, int n2) {
         const float* comb = combs + (size_t)slot * kStreamWaves * nq * cstride;
         for (int t = threadIdx.x; t < R * D; t += kStreamWaves * 64) {
@@ -1147,16 +1171,13 @@ void attn_kernel(const AttnParams p) {
                 acc += src[d] * c;
                 lt += src[D + 1] * c;
             }
-            float r = lt > 0.f ? acc / lt : 0.f;
-            if (QUANT && lt > 0.f) {   // (P.V / l + offset_v) * scale_v, …Us2.h:4160-4174
-                const long long pi = (long long)p.Hkv * D + (long long)n2 * D + d;   // value params follow the key params
-                if (p.antiq_offset) r += load_qk_elem(p.antiq_offset, p.q_dtype, pi);
-                r *= load_qk_elem(p.antiq_scale, p.q_dtype, pi);
+            if (NS == 1) {
+                store_out((long long)row0 + g, d, n2, acc, lt);
+            } else {   // this workgroup's share of the item: un-normalised state [nq][D + 2] of unit blockIdx.x
+                float* dst = p.split_partials + ((size_t)blockIdx.x * nq + g) * cstride;
+                dst[d] = acc;
+                if (d == 0) { dst[D] = mt; dst[D + 1] = lt; }
             }
-            const long long oi = ((long long)row0 + g) * D + d;
-            if (p.out_dtype == kF32) ((float*)p.out)[oi] = r;
-            else if (p.out_dtype == kBF16) ((__bf16*)p.out)[oi] = (__bf16)r;   // round to nearest even (…Us2.h:3476-3477)
-            else ((_Float16*)p.out)[oi] = (_Float16)r;
         }
     };
 
@@ -1202,6 +1223,7 @@ void attn_kernel(const AttnParams p) {
     while (true) {
         const int item = __builtin_amdgcn_readfirstlane(hdrs[slot].item);
         const int nU = __builtin_amdgcn_readfirstlane(hdrs[slot].nU);
+        const int lo = __builtin_amdgcn_readfirstlane(hdrs[slot].lo);
         const int n2 = __builtin_amdgcn_readfirstlane(hdrs[slot].n2);
         const int row0 = __builtin_amdgcn_readfirstlane(hdrs[slot].row0);
         const int R = __builtin_amdgcn_readfirstlane(hdrs[slot].R);
@@ -1211,12 +1233,12 @@ void attn_kernel(const AttnParams p) {
         else {
             if (wave == 0) SPFA_STAMP(8);
             if constexpr (MFMA)
-                stream_mfma<KVT, LPT>(p, lists + (size_t)slot * p.max_entries,
+                stream_mfma<KVT, LPT>(p, lists + (size_t)slot * p.max_entries + lo,
                                       combs + (size_t)slot * kStreamWaves * nq * cstride,
                                       smem + p.off_vst + (size_t)wave * (32 * (LPT * 16 + 32)), nU, n2, row0, R, nq,
                                       qscale, lane, wave);
             else
-                stream_valu<KVT, NQ, LPT>(p, lists + (size_t)slot * p.max_entries, qsts + (size_t)slot * nq * D,
+                stream_valu<KVT, NQ, LPT>(p, lists + (size_t)slot * p.max_entries + lo, qsts + (size_t)slot * nq * D,
                                           combs + (size_t)slot * kStreamWaves * nq * cstride, nU, n2, lane, wave);
             if (wave == 0) SPFA_STAMP(9);
         }
@@ -1228,25 +1250,47 @@ void attn_kernel(const AttnParams p) {
         prev_row0 = row0; prev_R = R; prev_n2 = n2; have_prev = true;
         slot ^= 1;
     }
+    if (NS > 1) {
+        // One unit per workgroup (grid == units), its state is in global memory.  Publish it (release), count
+        // arrivals per item, and let the last workgroup of an item merge the NS states (acquire) into the output.
+        __threadfence();
+        __syncthreads();
+        const int item = (int)blockIdx.x / NS;
+        if (threadIdx.x == 0) team[2] = (int)atomicAdd(p.split_done + item, 1u);
+        __syncthreads();
+        if (team[2] == NS - 1) {
+            __threadfence();
+            const ItemCtx c = decode((int)blockIdx.x);
+            const float* parts = p.split_partials + (size_t)item * NS * nq * cstride;
+            for (int t = threadIdx.x; t < c.R * D; t += WAVES * 64) {
+                const int g = t / D, d = t - g * D;
+                float mt = kNegBig;
+                for (int u = 0; u < NS; ++u) mt = fmaxf(mt, parts[((size_t)u * nq + g) * cstride + D]);
+                float acc = 0.f, lt = 0.f;
+                for (int u = 0; u < NS; ++u) {
+                    const float* src = parts + ((size_t)u * nq + g) * cstride;
+                    const float cf = fast_exp2(src[D] - mt);
+                    acc += src[d] * cf;
+                    lt += src[D + 1] * cf;
+                }
+                store_out(c.row0 + g, d, c.n2, acc, lt);
+            }
+        }
+    }
 }
 
 template <typename KVT, int NQ, int LPT, bool MFMA>
 hipError_t launch_attn_one(const AttnParams& p, hipStream_t s) {
     auto kern = attn_kernel<KVT, NQ, LPT, MFMA>;
-    static int n_cu = 0;
     if (p.lds_bytes > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)p.lds_bytes);
         if (e != hipSuccess) return e;
     }
-    int dev = 0, occ = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    if (n_cu == 0) {
-        e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-        if (e != hipSuccess) return e;
-    }
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, attn_threads(MFMA), p.lds_bytes);
+    int occ = 0;
+    const int n_cu = device_cu_count();
+    if (n_cu <= 0) return hipErrorNoDevice;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, attn_threads(MFMA), p.lds_bytes);
     if (e != hipSuccess) return e;
     int blocks_per_cu = occ < 1 ? 1 : occ;   // residency of the persistent grid
     // 8 streamer waves per CU already saturate HBM; a third workgroup only deepens the memory queues
@@ -1254,9 +1298,10 @@ hipError_t launch_attn_one(const AttnParams& p, hipStream_t s) {
     const bool per_head = (p.mode == 0 && p.pos_rows == p.Hq && p.G > 1);
     const int g_eff = per_head ? 1 : p.G;
     const int nq = MFMA ? p.rows_per_pass : NQ;
-    const long long total = (long long)p.B * (per_head ? p.Hq : p.Hkv) * ((g_eff + nq - 1) / nq);
+    const long long total = (long long)p.B * (per_head ? p.Hq : p.Hkv) * ((g_eff + nq - 1) / nq) * p.n_split;
     if (total == 0) return hipSuccess;
     const long long cap = (long long)n_cu * blocks_per_cu;
+    if (p.n_split > 1 && total > cap) return hipErrorInvalidConfiguration;   // a split needs one workgroup per unit
     const dim3 grid((unsigned)(total < cap ? total : cap));
     static bool said = false;
     if (!said && getenv("SPFA_DEBUG")) {
@@ -1297,6 +1342,13 @@ hipError_t launch_attn_mfma(const AttnParams& p, int lpt, hipStream_t s) {
 }
 
 }  // namespace
+
+int device_cu_count() {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    return n;
+}
 
 bool attention_uses_mfma(int rows_per_pass, int kv_dtype) { return rows_per_pass > 1 && kv_dtype != kI8; }
 

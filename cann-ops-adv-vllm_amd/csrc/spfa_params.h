@@ -82,6 +82,10 @@ struct AttnParams {
     int rows_per_pass;             // q heads of a group handled per pass
     int max_entries;               // capacity of the per-workgroup page list
     unsigned* counters;            // 8 work counters (workspace), zeroed before every launch
+    // page-list split for small batches: n_split workgroups per item (1: off)
+    int n_split;
+    unsigned* split_done;          // [items] arrival counters (workspace), zeroed before every launch
+    float* split_partials;         // [items * n_split][rows_per_pass][D + 2] un-normalised states (workspace)
     unsigned long long* debug;     // diagnostic builds only: [grid][16 items][16 stamps], else null
     // LDS carve (bytes from the dynamic base)
     int off_keys, off_cbits, off_pbits, off_list, off_comb, off_qst, off_hdr, off_vst;
@@ -92,6 +96,8 @@ hipError_t launch_compute_cent(const CentParams& p, hipStream_t s);
 hipError_t launch_cent_select(const CentParams& p, hipStream_t s);
 hipError_t launch_select_position(const SelectParams& p, hipStream_t s);
 hipError_t launch_attention(const AttnParams& p, hipStream_t s);
+// Compute units of the current device (0 when no device can be queried).
+int device_cu_count();
 // Number of q heads of a group one pass over the K/V pages serves, and whether that pass runs on the MFMA streamer
 // (which stages V tiles in LDS: 4 waves x 32 rows x (2 D + 32) bytes at off_vst).
 int attention_rows_per_pass(int G, int kv_dtype);

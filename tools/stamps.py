@@ -66,9 +66,15 @@ d = report("fused", plan.run)
 row = d[:, 0, :]
 ok = row[:, 11] > 0
 t_first = row[ok, 11].min()
-print(f"prologue: kernel-start spread={np.median(row[ok, 11] - t_first):.0f} score={np.median(row[ok, 12] - row[ok, 11]):.0f} "
+ends = d[:, :, 10].max(axis=1)[ok] - row[ok, 11]   # s_memtime bases differ between XCDs: only own-start deltas
+print(f"prologue: start-spread(p50/max)={np.median(row[ok, 11] - t_first):.0f}/{(row[ok, 11] - t_first).max():.0f} "
+      f"score={np.median(row[ok, 12] - row[ok, 11]):.0f} "
       f"rows={np.median((row[ok, 13] - row[ok, 12])[row[ok, 13] > 0]) if (row[ok, 13] > 0).any() else 0:.0f} "
-      f"end-start={np.median(row[ok, 14] - row[ok, 11]):.0f} last_end={(d[:, :, 9].max() - t_first)}")
+      f"end-start={np.median(row[ok, 14] - row[ok, 11]):.0f}")
+print("workgroup durations (ticks from its own start): " +
+      " ".join(f"p{q}={np.percentile(ends, q):.0f}" for q in (0, 10, 50, 90, 100)))
+n_items = (d[:, :, 8] > 0).sum(axis=1)[ok]
+print("items per workgroup: " + " ".join(f"{k}:{int((n_items == k).sum())}" for k in sorted(set(n_items.tolist()))))
 names = {(0, 1): "fetch", (1, 2): "score", (2, 3): "topk", (3, 4): "select", (4, 5): "union", (5, 6): "qstage"}
 for it in range(5):
     row = d[:, it, :]
