@@ -50,6 +50,7 @@ thread_local std::string g_err;
 thread_local int64_t g_topk = 64;
 thread_local int g_sink_recent = 0;
 thread_local int g_page_cap = 0;
+thread_local int g_max_split = 16;
 thread_local int64_t g_page_size = 128;   // PAGESIZE of cent_select.cpp:17 / select_position.cpp:112
 thread_local const long long* g_act_seq_dev = nullptr;   // one-shot, consumed by the next attention plan
 thread_local int64_t g_act_seq_dev_n = 0;
@@ -239,6 +240,11 @@ aclnnStatus spfaSetTopK(int64_t k) {
 }
 aclnnStatus spfaSetSinkRecent(int enable) { g_sink_recent = enable ? 1 : 0; return ACLNN_SUCCESS; }
 aclnnStatus spfaSetPageCap(int enable) { g_page_cap = enable ? 1 : 0; return ACLNN_SUCCESS; }
+aclnnStatus spfaSetMaxSplit(int64_t max_split) {
+    if (max_split < 1 || max_split > 16) return fail(ACLNN_ERR_PARAM_INVALID, "max split %lld out of [1, 16]", (long long)max_split);
+    g_max_split = (int)max_split;
+    return ACLNN_SUCCESS;
+}
 aclnnStatus spfaSetPageSize(int64_t page_size) {
     if (page_size < 1 || page_size > 512) return fail(ACLNN_ERR_PARAM_INVALID, "page size %lld out of [1, 512]", (long long)page_size);
     g_page_size = page_size;
@@ -588,7 +594,7 @@ static void plan_workspace(aclOpExecutor* e) {
     const int n_cu = spfa::device_cu_count();
     if (items > 0 && items * 2 <= n_cu) {
         long long ns = n_cu / items;
-        if (ns > 16) ns = 16;
+        if (ns > g_max_split) ns = g_max_split;
         if (ns > p.max_entries) ns = p.max_entries;   // at least one page per share
         if (ns > 1) p.n_split = (int)ns;
     }

@@ -94,6 +94,10 @@ SPFA_API void ReleaseHugeMem(void* arg, bool sync);
 SPFA_API aclnnStatus spfaSetTopK(int64_t k);
 SPFA_API aclnnStatus spfaSetSinkRecent(int enable);
 SPFA_API aclnnStatus spfaSetPageCap(int enable);
+/* Small batches (fewer items than half the compute units): the two attention ops deal each item's page list to up
+ * to maxSplit workgroups and merge their states in the same launch; the reported workspace size grows by the
+ * states.  1 turns the split off.  Default 16, range [1, 16]. */
+SPFA_API aclnnStatus spfaSetMaxSplit(int64_t maxSplit);
 /* page size of the two ops without a blockSize attribute (CentSelect, SelectPosition); the reference
  * compiles in 128 (cent_select.cpp:17, select_position.cpp:112).  Default 128. */
 SPFA_API aclnnStatus spfaSetPageSize(int64_t pageSize);

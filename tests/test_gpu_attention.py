@@ -288,3 +288,41 @@ def test_attention_abi_errors(H):
         H.call_attention(q, kv.to(torch.int8), kv.to(torch.int8), table, pos, [128], 4, 4, 1.0, 128)
     with pytest.raises(AclError, match="blockposition"):
         H.call_attention(q, kv, kv, table, H.dev(np.zeros((1, 3, 4), np.int32)), [128], 4, 4, 1.0, 128)
+
+
+@pytest.mark.parametrize("Hq,Hkv,kvdt", [(8, 8, "f16"), (8, 2, "bf16"), (8, 2, "i8")])
+def test_page_list_split_equals_single_workgroup(H, Hq, Hkv, kvdt):
+    """A small batch is dealt to several workgroups per item; with the split turned off the same launch runs one
+    workgroup per item.  Integer outputs must be identical, the attention equal up to the merge order."""
+    from custom_ops import _abi
+    D, C, topk, bs = 128, 256, 8, 128
+    seq_lens = [70 * bs + 9, 3 * bs, 1]
+    B = len(seq_lens)
+    q, l1, ids, table, seq, k, v = _fusion_case(77, B, Hq, Hkv, D, C, seq_lens, 96, 80, bs,
+                                                kv="i8" if kvdt == "i8" else "f16")
+    tdt = torch.bfloat16 if kvdt == "bf16" else torch.float16
+    kd, vd = (H.dev(k), H.dev(v)) if kvdt == "i8" else (H.dev(k, tdt), H.dev(v, tdt))
+    qd, l1d, td, idsd, seqd = H.dev(q, tdt), H.dev(l1, tdt), H.dev(table), H.dev(ids), H.dev(seq)
+    kw = {}
+    if kvdt == "i8":
+        a_s, a_o = datagen.antiquant_case(5, Hkv, D, True)
+        kw = dict(antiq_scale=H.dev(a_s), antiq_offset=H.dev(a_o))
+    res = {}
+    for max_split in (1, 16, 3):
+        _abi.check(_abi.spfaSetMaxSplit(max_split), "spfaSetMaxSplit")
+        try:
+            res[max_split] = H.call_fusion(qd, kd, vd, td, l1d, idsd, seqd, Hq, Hkv, D ** -0.5, bs, topk,
+                                           out_dtype=torch.float32, **kw)
+            spos = res[max_split][1]
+            sep = H.call_attention(qd, kd, vd, td, spos, torch.tensor([10 ** 9] * B), Hq, Hkv, D ** -0.5, bs,
+                                   out_dtype=torch.float32, **kw)
+            res[("sep", max_split)] = sep
+        finally:
+            _abi.spfaSetMaxSplit(16)
+    out1, pos1, len1, max1 = res[1]
+    scale = float(out1.abs().max())
+    for ms in (16, 3):
+        out, pos, plen, pmax = res[ms]
+        assert torch.equal(pos, pos1) and torch.equal(plen, len1) and torch.equal(pmax, max1)
+        assert float((out - out1).abs().max()) <= 2e-6 * scale
+        assert float((res[("sep", ms)] - res[("sep", 1)]).abs().max()) <= 2e-6 * scale
