@@ -188,15 +188,26 @@ def cpu_baseline(a, wl, custom_ops, plan_args):
 
 def main():
     a = parse()
+    if os.environ.get("BENCH_WATCHDOG"):   # rehearsal aid: dump every thread's stack and exit if the run stalls
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["BENCH_WATCHDOG"]), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # Rehearsal on a one-GPU box: BENCH_SINGLE_DEVICE=1 puts every rank on cuda:0 and BENCH_DIST_BACKEND=gloo replaces
+    # RCCL (which refuses two ranks on one device); the driver's multi-GPU runs use neither.
+    if os.environ.get("BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     import custom_ops

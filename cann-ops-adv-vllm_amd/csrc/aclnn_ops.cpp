@@ -134,13 +134,21 @@ int to_dtype(aclDataType t) {
 
 int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
-// q heads of one group that can be scored per pass: keys [rows][Cp] u32 must fit a 64 KiB budget
-int score_rows_per_pass(int G, int Cp, int cap) {
-    int r = (64 * 1024) / (Cp * 4);
+// q rows scored per centroid pass by the standalone scoring ops: the keys [rows][Cp] u32 must fit a 64 KiB budget
+// (two workgroups per CU), at most 16 rows (one MFMA tile).  When a whole group fits, rows of several sequences
+// share the pass.
+void plan_cent_rows(spfa::CentParams& p) {
+    int r = (64 * 1024) / (p.Cp * 4);
     if (r < 1) r = 1;
-    if (r > cap) r = cap;
-    if (r > G) r = G;
-    return r;
+    if (r > 16) r = 16;
+    if (p.G >= r) {                 // the group alone fills (or exceeds) a pass
+        p.rows_per_pass = r;
+        p.seq_per_group = 1;
+    } else {
+        p.seq_per_group = r / p.G;
+        if (p.seq_per_group > p.B) p.seq_per_group = p.B > 0 ? p.B : 1;
+        p.rows_per_pass = p.seq_per_group * p.G;
+    }
 }
 
 aclnnStatus check_qcent(const aclTensor* query, const aclTensor* l1, int* Hq, int* Hkv, int* D, int* C) {
@@ -284,7 +292,7 @@ aclnnStatus aclnnComputeCentGetWorkspaceSize(const aclTensor* query, const aclTe
     p.qk_dtype = to_dtype(query->dtype);
     p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.G = Hq / Hkv; p.D = D; p.C = C; p.k = k;
     p.Cp = round_up(C, 128);
-    p.rows_per_pass = score_rows_per_pass(p.G, p.Cp, 8);
+    plan_cent_rows(p);
     p.indices = (int32_t*)data_ptr(indicesOut);
     int npow2 = 64;
     while (npow2 < k) npow2 <<= 1;
@@ -395,7 +403,7 @@ aclnnStatus aclnnCentSelectGetWorkspaceSize(const aclTensor* query, const aclTen
     p.qk_dtype = to_dtype(query->dtype);
     p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.G = Hq / Hkv; p.D = D; p.C = C; p.k = k;
     p.Cp = round_up(C, 128);
-    p.rows_per_pass = score_rows_per_pass(p.G, p.Cp, 8);
+    plan_cent_rows(p);
     p.block_ids = (const int32_t*)data_ptr(blockIds);
     p.block_table = (const int32_t*)data_ptr(blockTable);
     p.seq_len = (const int32_t*)data_ptr(seqLen);

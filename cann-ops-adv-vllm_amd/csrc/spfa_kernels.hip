@@ -1,24 +1,26 @@
 // gfx950 (MI355X / CDNA4) kernels for the sparse paged fusion attention chain:
 //   ComputeCent -> CentSelect / SelectPosition -> SparsePagedAttention, and the fused op.
 //
-// Design (wave64, 4 waves per workgroup, one workgroup per (batch, kv head)):
-//   * Q.Cent^T   : v_mfma_f32_16x16x32_{f16,bf16}; A = the group's q heads (zero padded to 16
+// Building blocks (all wave64):
+//   * Q.Cent^T   : v_mfma_f32_16x16x32_{f16,bf16}; A = the q heads of one kv head (zero padded to 16
 //                  rows), B = 16 centroid rows loaded 16 B per lane straight from global/L2.
 //                  fp16 x fp16 products are exact in fp32, accumulation is fp32 like the
 //                  reference's MulAddDst (compute_cent.cpp:279-340).
 //   * top-k      : one wave per q head.  Scores become order-preserving uint32 keys in LDS; the
-//                  k-th largest key is found by a 32-step bitwise bisection whose counts are
-//                  wave ballots, ties are broken by ascending cluster id.  The k ids become a
-//                  C-bit bitmap in LDS (cent_select / fused) or are sorted descending (compute_cent).
-//   * page select: 64 logical pages per step: cluster id = block_ids[kv][block_table[b][i]],
+//                  k-th largest key is found by an integer bisection whose full steps count with one
+//                  compare per key and whose late steps run on at most 64 compacted candidates; ties
+//                  are broken by ascending cluster id.  The k ids become a C-bit bitmap in LDS
+//                  (cent_select / fused) or are sorted descending (compute_cent).
+//   * page select: 256 logical pages per step: cluster id = block_ids[kv][block_table[b][i]],
 //                  membership = one bitmap probe, ballot + prefix popcount gives the output slot,
 //                  so page_position is written in ascending order with coalesced int32 stores.
-//   * attention  : HBM-bound (2*G flop per KV byte).  K/V rows go from HBM straight to VGPRs with
-//                  16 B per lane (a 256 B fp16 head row = 16 lanes), every 16-lane token group keeps
-//                  its own online-softmax state (m, l, o) so the page loop has no cross-lane traffic
-//                  beyond a 16-lane DPP reduction of the dot product; states are merged once at the
-//                  end (shuffles inside a wave, LDS across the 4 waves).  A GQA group walks the
-//                  UNION of its heads' page lists once; a per-page head mask gates each head.
+//   * attention  : HBM-bound (2*G flop per KV byte).  A persistent grid of workgroups pulls (batch,
+//                  kv head) items from a queue; selector wave(s) prepare the next item's page list
+//                  while four streamer waves read the current item's K/V pages.  One q head per
+//                  item: K/V rows go from HBM straight to VGPRs and every 16-lane token group keeps
+//                  its own online-softmax state (stream_valu).  Several q heads per item (GQA): the
+//                  matrix pipe does K.Q^T and V^T.P^T per 32-token tile (stream_mfma).  A GQA group
+//                  walks the UNION of its heads' page lists once; a per-page head mask gates each head.
 //   * int8 KV    : dequant is fused into the load path: q' = q * scale_k, bytes are converted with
 //                  v_cvt_f32_ubyte after flipping the sign bit (u = x + 128), the -128 bias is
 //                  folded into the accumulators, out = (P.V / l + offset_v) * scale_v
@@ -88,9 +90,11 @@ __device__ __forceinline__ float load_qk_elem(const void* p, int dtype, long lon
 // KS = D / 32 MFMA k-steps.  All 16 loads of a group of tiles are issued before the first MFMA (no branch
 // sits between them: dtype and KS are template parameters, out-of-range centroids are clamped and masked at
 // the store), so one round trip to L2 brings 16 KiB per wave instead of 1 KiB.
+// Row r of the tile is q row q_row0 + (r / rpb) * b_stride + r % rpb: rpb consecutive heads of one sequence, then the
+// same heads of the next sequence b_stride rows further (rpb = R: all rows consecutive).
 template <int WAVES, bool BF16, int KS>
 __device__ __forceinline__ void score_rows_impl(const void* q, const void* cent, long long q_row0, int n2, int R,
-                                                int C, int Cp, uint32_t* keys, int wave) {
+                                                int C, int Cp, uint32_t* keys, int wave, int rpb, int b_stride) {
     constexpr int D = KS * 32;
     constexpr int TG = 16 / KS;   // tiles per group: TG * KS = 16 loads in flight
     const int lane = lane_id();
@@ -100,7 +104,9 @@ __device__ __forceinline__ void score_rows_impl(const void* q, const void* cent,
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
         qa[kk] = make_uint4(0, 0, 0, 0);
-        if (col < R) qa[kk] = *(const uint4*)((const char*)q + ((q_row0 + col) * D + kk * 32 + kq * 8) * 2);
+        if (col < R)
+            qa[kk] = *(const uint4*)((const char*)q +
+                                     ((q_row0 + (long long)(col / rpb) * b_stride + col % rpb) * D + kk * 32 + kq * 8) * 2);
     }
     const char* cbase = (const char*)cent + (long long)n2 * C * D * 2 + kq * 16;
     const int ntiles = Cp >> 4;   // Cp % 128 == 0: a multiple of every TG
@@ -138,11 +144,12 @@ __device__ __forceinline__ void score_rows_impl(const void* q, const void* cent,
 // widx: this wave's index among the WAVES waves that share the tiles.
 template <int WAVES>
 __device__ __forceinline__ void score_rows(const void* q, const void* cent, int dtype, long long q_row0,
-                                           int n2, int R, int D, int C, int Cp, uint32_t* keys, int widx) {
+                                           int n2, int R, int D, int C, int Cp, uint32_t* keys, int widx,
+                                           int rpb = 16, int b_stride = 0) {
 #define SPFA_SCORE(KS)                                                                              \
     case KS:                                                                                        \
-        if (dtype == kBF16) score_rows_impl<WAVES, true, KS>(q, cent, q_row0, n2, R, C, Cp, keys, widx);  \
-        else score_rows_impl<WAVES, false, KS>(q, cent, q_row0, n2, R, C, Cp, keys, widx);                \
+        if (dtype == kBF16) score_rows_impl<WAVES, true, KS>(q, cent, q_row0, n2, R, C, Cp, keys, widx, rpb, b_stride);  \
+        else score_rows_impl<WAVES, false, KS>(q, cent, q_row0, n2, R, C, Cp, keys, widx, rpb, b_stride);                \
         break;
     switch (D >> 5) {
         SPFA_SCORE(1)
@@ -385,32 +392,38 @@ __device__ __forceinline__ int select_pages(const uint32_t* cbits, int C, const 
 // ------------------------------------------------------------------------------------------------
 // compute_cent / cent_select kernel
 // ------------------------------------------------------------------------------------------------
+// One workgroup per (kv head, group of BG sequences): the BG * G q rows that share the head's centroids are
+// scored in ONE pass over them (up to 16 MFMA rows), so a centroid slice is read once per group instead of
+// once per q row (reference: cent_select.cpp:228-231) or once per sequence.  Groups larger than the key area
+// (G > rows_per_pass) fall back to BG = 1 and several passes.  Then one wave per q row.
 template <int MODE>   // 0: compute_cent, 1: cent_select
 __global__ __launch_bounds__(kThreads) void cent_kernel(const CentParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = lane_id(), wave = wave_id();
-    const int n2 = blockIdx.x % p.Hkv;   // blocks b and b+8 share an XCD: one kv head's centroids
-    const int b = blockIdx.x / p.Hkv;    // stay in that XCD's L2
+    const int n2 = blockIdx.x % p.Hkv;   // blocks i and i+8 share an XCD: one kv head's centroids
+    const int b0 = (blockIdx.x / p.Hkv) * p.seq_per_group;   // stay in that XCD's L2
     const int RG = p.rows_per_pass;
     uint32_t* keys = (uint32_t*)smem;                                  // [RG][Cp]
     char* aux = smem + (size_t)RG * p.Cp * 4;
-    int page_len = 0;
-    if (MODE == 1) page_len = (p.seq_len[b] + p.block_size - 1) / p.block_size;   // cent_select.cpp:217
-    page_len = max(0, min(page_len, p.max_page));
-    int len_max = 0;
+    const int nb = min(p.seq_per_group, p.B - b0);                     // sequences of this workgroup
+    const int rpb = min(p.G, RG);                                      // rows per sequence in one pass
     for (int g0 = 0; g0 < p.G; g0 += RG) {
-        const int R = min(RG, p.G - g0);
-        const long long row0 = (long long)b * p.Hq + (long long)n2 * p.G + g0;
-        score_rows<4>(p.q, p.cent, p.qk_dtype, row0, n2, R, p.D, p.C, p.Cp, keys, wave);
+        const int Rg = min(RG, p.G - g0);                              // heads of this pass (per sequence)
+        const int R = nb * Rg;
+        const long long row0 = (long long)b0 * p.Hq + (long long)n2 * p.G + g0;
+        score_rows<4>(p.q, p.cent, p.qk_dtype, row0, n2, R, p.D, p.C, p.Cp, keys, wave, nb > 1 ? rpb : R, p.Hq);
         __syncthreads();
         for (int r = wave; r < R; r += 4) {
-            const long long row = row0 + r;
+            const int b = b0 + (nb > 1 ? r / rpb : 0);
+            const long long row = row0 + (long long)(nb > 1 ? r / rpb : 0) * p.Hq + (nb > 1 ? r % rpb : r);
             if (MODE == 0) {
                 int npow2 = 64;
                 while (npow2 < p.k) npow2 <<= 1;
                 unsigned long long* sortbuf = (unsigned long long*)aux + (size_t)wave * npow2;
                 topk_sorted(keys + r * p.Cp, p.Cp, p.k, npow2, sortbuf, p.indices + row * p.k, lane);
             } else {
+                int page_len = (p.seq_len[b] + p.block_size - 1) / p.block_size;   // cent_select.cpp:217
+                page_len = max(0, min(page_len, p.max_page));
                 uint32_t* cbits = (uint32_t*)aux + (size_t)wave * (p.Cp >> 5);
                 topk_bitmap(keys + r * p.Cp, p.Cp, p.k, cbits, lane);
                 wave_lds_sync();
@@ -418,15 +431,16 @@ __global__ __launch_bounds__(kThreads) void cent_kernel(const CentParams p) {
                                              p.block_ids + (long long)n2 * p.kv_page_len, p.kv_page_len,
                                              page_len, p.P, p.sink_recent, p.cap_pages,
                                              p.page_position + row * p.P, nullptr, 0, lane);
-                if (lane < kLenPad) p.page_position_length[row * kLenPad + lane] = len;   // cent_select.cpp:418
-                len_max = max(len_max, len);
+                if (lane < kLenPad) {
+                    p.page_position_length[row * kLenPad + lane] = len;   // cent_select.cpp:418
+                    if (len > 0)   // cent_select.cpp:124-152: max_h(len) * page size
+                        atomicMax(p.max_page_position_length + (long long)b * kLenPad + lane,
+                                  (unsigned long long)len * (unsigned long long)p.block_size);
+                }
             }
         }
         __syncthreads();
     }
-    if (MODE == 1 && lane < kLenPad && len_max > 0)   // cent_select.cpp:124-152: max_h(len) * page size
-        atomicMax(p.max_page_position_length + (long long)b * kLenPad + lane,
-                  (unsigned long long)len_max * (unsigned long long)p.block_size);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -472,10 +486,11 @@ __global__ __launch_bounds__(kThreads) void select_position_kernel(const SelectP
 // ------------------------------------------------------------------------------------------------
 // attention: persistent, wave-specialised kernel
 //
-//   work item  = (batch, kv head, pass of up to NQ q heads)          [per-head lists: (batch, q head)]
-//   workgroup  = 5 waves: waves 0-3 stream K/V pages of the CURRENT item, wave 4 (the selector)
-//                prepares the NEXT item meanwhile: Q.Cent^T, top-k, page selection, the union page
-//                list and the pre-scaled q rows go into the other half of a double-buffered LDS area.
+//   work item  = (batch, kv head, pass of up to rows_per_pass q heads)   [per-head lists: (batch, q head)]
+//   workgroup  = waves 0-3 stream K/V pages of the CURRENT item, the selector wave(s) behind them (one, or a
+//                team of two when an item carries several q heads) prepare the NEXT item meanwhile: Q.Cent^T,
+//                top-k, page selection, the union page list and the pre-scaled q rows go into the other half
+//                of a double-buffered LDS area.
 //   One __syncthreads() per item hands the buffers over.  Selection work (latency bound, no HBM
 //   traffic) is therefore hidden behind the HBM-bound page stream instead of preceding it.
 //   Items are pulled from 8 counters (one per XCD class, item % 8) so that the kv heads an XCD works on
@@ -1385,7 +1400,7 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
 }
 
 static hipError_t launch_cent(const CentParams& p, int mode, hipStream_t s) {
-    const dim3 grid((unsigned)((long long)p.B * p.Hkv));
+    const dim3 grid((unsigned)((long long)((p.B + p.seq_per_group - 1) / p.seq_per_group) * p.Hkv));
     if (grid.x == 0) return hipSuccess;
     const void* kern = mode == 0 ? (const void*)cent_kernel<0> : (const void*)cent_kernel<1>;
     if (p.lds_bytes > 48 * 1024) {

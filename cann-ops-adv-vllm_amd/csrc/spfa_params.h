@@ -14,13 +14,14 @@ constexpr int kThreads = 256;           // 4 wave64 per workgroup
 
 enum DType : int { kF16 = 0, kBF16 = 1, kI8 = 2, kF32 = 3 };
 
-// ComputeCent / CentSelect (no attention).  One workgroup per (batch, kv head).
+// ComputeCent / CentSelect (no attention).  One workgroup per (group of sequences, kv head).
 struct CentParams {
     const void* q;             // [Bq, Hq, D]   f16 | bf16
     const void* cent;          // [Hkv, C, D]   same dtype
     int qk_dtype;              // kF16 | kBF16
     int B, Hq, Hkv, G, D, C, k;
-    int rows_per_pass;         // q heads of a group scored per pass (LDS budget)
+    int rows_per_pass;         // q rows scored per centroid pass (LDS budget of the keys, <= 16)
+    int seq_per_group;         // sequences whose rows share one pass (rows_per_pass / G when G fits, else 1)
     int Cp;                    // C rounded up to 64
     // mode 0: compute_cent (sorted indices out)
     int32_t* indices;          // [B, Hq, k]
