@@ -564,7 +564,7 @@ static size_t carve_lds(spfa::AttnParams& p, size_t nq) {
     p.off_comb = (int)off;
     off += align16((size_t)2 * 4 * nq * (p.D + 2) * 4);                    // streamer states of two items
     p.off_qst = (int)off;
-    const bool mfma = spfa::attention_uses_mfma((int)nq, p.kv_dtype);
+    const bool mfma = spfa::attention_uses_mfma((int)nq, p.kv_dtype, p.D);
     if (!mfma) off += align16((size_t)2 * nq * p.D * 4);                   // pre-scaled q rows (VALU streamer)
     p.off_hdr = (int)off;
     off += 2 * 32 + 16;                                                    // two item headers + selector team words
@@ -575,10 +575,10 @@ static size_t carve_lds(spfa::AttnParams& p, size_t nq) {
 
 static aclnnStatus plan_lds(spfa::AttnParams& p) {
     const bool per_head = (p.mode == 0 && p.pos_rows == p.Hq && p.G > 1);
-    int nq = per_head ? 1 : spfa::attention_rows_per_pass(p.G, p.kv_dtype);
+    int nq = per_head ? 1 : spfa::attention_rows_per_pass(p.G, p.kv_dtype, p.D);
     size_t need = carve_lds(p, (size_t)nq);
     // a large group with many clusters: fewer q heads per pass (more passes over the pages) until the keys fit
-    while (need > kMaxLds && nq > 2 && spfa::attention_uses_mfma(nq, p.kv_dtype)) {
+    while (need > kMaxLds && nq > 2 && spfa::attention_uses_mfma(nq, p.kv_dtype, p.D)) {
         nq = (nq + 1) / 2;
         need = carve_lds(p, (size_t)nq);
     }

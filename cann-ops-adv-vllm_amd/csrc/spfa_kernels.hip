@@ -750,7 +750,8 @@ __device__ __forceinline__ void stream_valu(const AttnParams& p, const PageEntry
 }
 
 // ------------------------------------------------------------------------------------------------
-// Streamer, MFMA form (2..16 q heads of a group share every K/V row; f16 / bf16 KV).
+// Streamer, MFMA form (2..16 q heads of a group share every K/V row; f16 / bf16 KV, or int8 KV converted to f16
+// on the way into the matrix pipe).
 //
 // Per 32-token tile of a page, one wave computes with v_mfma_f32_16x16x32:
 //   S^T[token][head] = K . Q^T     A = K rows straight from HBM (lane: token l&15, 16-byte slice l>>4 of each
@@ -772,23 +773,61 @@ __device__ __forceinline__ void stream_mfma(const AttnParams& p, const PageEntry
                                             int nU, int n2, long long row0, int R, int nq, float qscale,
                                             int lane, int wave) {
     constexpr bool BF16 = __is_same(KVT, __bf16);
-    constexpr int D = LPT * 8;
+    constexpr bool I8 = sizeof(KVT) == 1;
+    constexpr int ES = (int)sizeof(KVT);
+    constexpr int D = LPT * 16 / ES;
     constexpr int KS = D / 32;                  // MFMA k steps of Q.K^T
+    constexpr int KL = I8 ? KS / 2 : KS;        // 16-byte K loads per lane and 16-token half
     constexpr int DT = D / 16;                  // 16-row tiles of O^T
     constexpr int TPL = 64 / LPT;               // V rows per wave load
     constexpr int VL = 32 / TPL;                // V wave loads per tile
-    constexpr int RS = D * 2 + 32;              // LDS row stride of the V image
+    constexpr int RS = D * 2 + 32;              // LDS row stride of the (16-bit) V image
     constexpr bool PREFETCH = SPFA_MFMA_PREFETCH && LPT <= 16;   // two tiles of registers fit
     constexpr float kNegBig = -1.0e30f;
     typedef short short4v __attribute__((ext_vector_type(4)));
+    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
     const int h = lane & 15, sg = lane >> 4;
     const int cstride = D + 2;
 
-    uint4 qf[KS];
+    // int8 -> f16, exact: flip the sign bit (u = x + 128), splice each byte under the exponent of 1024.0
+    // (0x6400 | u = 1024 + u) and subtract 1152.  One dword (4 values) -> two packed-f16 dwords in 5 VALU ops.
+    auto cvt4 = [](uint32_t w, uint32_t& lo, uint32_t& hi) {
+        const uint32_t u = w ^ 0x80808080u;
+        const half2v bias = {(_Float16)1152.f, (_Float16)1152.f};
+        lo = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2v, __builtin_amdgcn_perm(0x64646464u, u, 0x04010400u)) - bias);
+        hi = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2v, __builtin_amdgcn_perm(0x64646464u, u, 0x04030402u)) - bias);
+    };
+    auto cvt16 = [&](const uint4& v, uint4& a, uint4& b) {   // 16 int8 -> two 8 x f16 fragments, element order kept
+        cvt4(v.x, a.x, a.y); cvt4(v.y, a.z, a.w);
+        cvt4(v.z, b.x, b.y); cvt4(v.w, b.z, b.w);
+    };
+
+    // B operand of K.Q^T: q head h (column), this lane's 8 elements of every k step.  f16 / bf16: the q row as it is,
+    // element kk * 32 + sg * 8 + j.  int8 KV: q' = q * scale_k per channel (…Us2.h:2647) as a high and a low f16
+    // part; a lane's K bytes are the 32 consecutive channels sg * (D / 4) ..., so step kk takes channels
+    // (kk / 2) * 64 + sg * 16 + (kk % 2) * 8 + j.
+    uint4 qf[KS], qlo[I8 ? KS : 1];
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
         qf[kk] = make_uint4(0, 0, 0, 0);
-        if (h < R) qf[kk] = *(const uint4*)((const char*)p.q + ((row0 + h) * D + kk * 32 + sg * 8) * 2);
+        if constexpr (I8) {
+            qlo[kk] = make_uint4(0, 0, 0, 0);
+            if (h < R) {
+                const int d0 = (kk >> 1) * 64 + sg * 16 + (kk & 1) * 8;
+                half8 hi8, lo8;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float x = load_qk_elem(p.q, p.q_dtype, (row0 + h) * D + d0 + j) *
+                                    load_qk_elem(p.antiq_scale, p.q_dtype, (long long)n2 * D + d0 + j);
+                    hi8[j] = (_Float16)x;
+                    lo8[j] = (_Float16)(x - (float)hi8[j]);
+                }
+                qf[kk] = __builtin_bit_cast(uint4, hi8);
+                qlo[kk] = __builtin_bit_cast(uint4, lo8);
+            }
+        } else {
+            if (h < R) qf[kk] = *(const uint4*)((const char*)p.q + ((row0 + h) * D + kk * 32 + sg * 8) * 2);
+        }
     }
     f32x4 o[DT];
 #pragma unroll
@@ -797,16 +836,16 @@ __device__ __forceinline__ void stream_mfma(const AttnParams& p, const PageEntry
 
     const int k_lane_off = h * (int)p.tok_stride + sg * 16;
     const int v_lane_off = (lane / LPT) * (int)p.tok_stride + (lane % LPT) * 16;
-    char* v_wr = vst + (lane / LPT) * RS + (lane % LPT) * 16;
+    char* v_wr = vst + (lane / LPT) * RS + (lane % LPT) * (I8 ? 32 : 16);
     // transposed read: lane 4q+pp of a 16-lane group addresses row q, columns 4pp..4pp+3 of the 16-column block
     const char* v_rd = vst + (4 * sg + (h >> 2)) * RS + (h & 3) * 8;
 
-    struct Tile { uint4 k[2][KS]; uint4 v[VL]; };
+    struct Tile { uint4 k[2][KL]; uint4 v[VL]; };
     auto issue = [&](Tile& T, const __amdgpu_buffer_rsrc_t& rk, const __amdgpu_buffer_rsrc_t& rv, int t0) {
 #pragma unroll
         for (int half = 0; half < 2; ++half)
 #pragma unroll
-            for (int kk = 0; kk < KS; ++kk)
+            for (int kk = 0; kk < KL; ++kk)
                 T.k[half][kk] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
                     rk, k_lane_off + kk * 64, (t0 + 16 * half) * (int)p.tok_stride, SPFA_KV_AUX));
 #pragma unroll
@@ -814,26 +853,48 @@ __device__ __forceinline__ void stream_mfma(const AttnParams& p, const PageEntry
             T.v[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
                 rv, v_lane_off, (t0 + i * TPL) * (int)p.tok_stride, SPFA_KV_AUX));
     };
+    auto mfma16 = [](const uint4& a, const uint4& b, f32x4 c) {
+        if constexpr (BF16)
+            return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+        else
+            return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
+    };
     auto compute = [&](const Tile& T, int t0, int valid, bool att) {
         f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (I8) {
+            f32x4 sa2 = {0.f, 0.f, 0.f, 0.f}, sb2 = {0.f, 0.f, 0.f, 0.f};   // the low parts: two more independent chains
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk) {
-            if constexpr (BF16) {
-                sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, T.k[0][kk]),
-                                                             __builtin_bit_cast(bf16x8, qf[kk]), sa, 0, 0, 0);
-                sb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, T.k[1][kk]),
-                                                             __builtin_bit_cast(bf16x8, qf[kk]), sb, 0, 0, 0);
-            } else {
-                sa = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, T.k[0][kk]),
-                                                            __builtin_bit_cast(half8, qf[kk]), sa, 0, 0, 0);
-                sb = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, T.k[1][kk]),
-                                                            __builtin_bit_cast(half8, qf[kk]), sb, 0, 0, 0);
+            for (int kl = 0; kl < KL; ++kl) {
+                uint4 a0, a1, b0, b1;
+                cvt16(T.k[0][kl], a0, a1);
+                cvt16(T.k[1][kl], b0, b1);
+                sa = mfma16(a0, qf[2 * kl], sa);      sa2 = mfma16(a0, qlo[2 * kl], sa2);
+                sb = mfma16(b0, qf[2 * kl], sb);      sb2 = mfma16(b0, qlo[2 * kl], sb2);
+                sa = mfma16(a1, qf[2 * kl + 1], sa);  sa2 = mfma16(a1, qlo[2 * kl + 1], sa2);
+                sb = mfma16(b1, qf[2 * kl + 1], sb);  sb2 = mfma16(b1, qlo[2 * kl + 1], sb2);
+            }
+            sa += sa2;
+            sb += sb2;
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                sa = mfma16(T.k[0][kk], qf[kk], sa);
+                sb = mfma16(T.k[1][kk], qf[kk], sb);
             }
         }
-        // V image of the tile: the previous tile's transposed reads were issued earlier by this same wave and
-        // LDS executes a wave's operations in order, so the area can be overwritten right away
+        // V image of the tile (16-bit, row major): the previous tile's transposed reads were issued earlier by this
+        // same wave and LDS executes a wave's operations in order, so the area can be overwritten right away
 #pragma unroll
-        for (int i = 0; i < VL; ++i) *(uint4*)(v_wr + i * TPL * RS) = T.v[i];
+        for (int i = 0; i < VL; ++i) {
+            if constexpr (I8) {
+                uint4 a, b;
+                cvt16(T.v[i], a, b);
+                *(uint4*)(v_wr + i * TPL * RS) = a;
+                *(uint4*)(v_wr + i * TPL * RS + 16) = b;
+            } else {
+                *(uint4*)(v_wr + i * TPL * RS) = T.v[i];
+            }
+        }
         float s[8];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -855,47 +916,41 @@ __device__ __forceinline__ void stream_mfma(const AttnParams& p, const PageEntry
         for (int dt = 0; dt < DT; ++dt) o[dt] *= alpha;
         asm volatile("" ::: "memory");   // the image is complete (in program order) before it is read back
         __builtin_amdgcn_wave_barrier();
+        uint4 ph, pl;
         if constexpr (BF16) {
-            bf16x8 ph, pl;
+            bf16x8 x, y;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                ph[j] = (__bf16)pr[j];
-                pl[j] = (__bf16)(pr[j] - (float)ph[j]);
+                x[j] = (__bf16)pr[j];
+                y[j] = (__bf16)(pr[j] - (float)x[j]);
             }
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                const short4v va = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) short4v*)(v_rd + dt * 32));
-                const short4v vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) short4v*)(v_rd + 16 * RS + dt * 32));
-                const uint4 vv = make_uint4(__builtin_bit_cast(uint2, va).x, __builtin_bit_cast(uint2, va).y,
-                                            __builtin_bit_cast(uint2, vb).x, __builtin_bit_cast(uint2, vb).y);
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vv), ph, o[dt], 0, 0, 0);
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vv), pl, o[dt], 0, 0, 0);
-            }
+            ph = __builtin_bit_cast(uint4, x);
+            pl = __builtin_bit_cast(uint4, y);
         } else {
-            half8 ph, pl;
+            half8 x, y;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                ph[j] = (_Float16)pr[j];
-                pl[j] = (_Float16)(pr[j] - (float)ph[j]);
+                x[j] = (_Float16)pr[j];
+                y[j] = (_Float16)(pr[j] - (float)x[j]);
             }
+            ph = __builtin_bit_cast(uint4, x);
+            pl = __builtin_bit_cast(uint4, y);
+        }
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                const short4v va = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) short4v*)(v_rd + dt * 32));
-                const short4v vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) short4v*)(v_rd + 16 * RS + dt * 32));
-                const uint4 vv = make_uint4(__builtin_bit_cast(uint2, va).x, __builtin_bit_cast(uint2, va).y,
-                                            __builtin_bit_cast(uint2, vb).x, __builtin_bit_cast(uint2, vb).y);
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, vv), ph, o[dt], 0, 0, 0);
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, vv), pl, o[dt], 0, 0, 0);
-            }
+        for (int dt = 0; dt < DT; ++dt) {
+            const short4v va = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) short4v*)(v_rd + dt * 32));
+            const short4v vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) short4v*)(v_rd + 16 * RS + dt * 32));
+            const uint4 vv = make_uint4(__builtin_bit_cast(uint2, va).x, __builtin_bit_cast(uint2, va).y,
+                                        __builtin_bit_cast(uint2, vb).x, __builtin_bit_cast(uint2, vb).y);
+            o[dt] = mfma16(vv, ph, o[dt]);
+            o[dt] = mfma16(vv, pl, o[dt]);
         }
         asm volatile("" ::: "memory");
     };
 
-    const int row_bytes = D * 2;
+    const int row_bytes = D * ES;
     // page cursor of this wave: pages wave, wave + 4, ... of the list, 32-token tiles inside a page
     int n = wave, t0 = 0, valid = 0;
     bool att = false;
@@ -1250,7 +1305,7 @@ void attn_kernel(const AttnParams p) {
             if constexpr (MFMA)
                 stream_mfma<KVT, LPT>(p, lists + (size_t)slot * p.max_entries + lo,
                                       combs + (size_t)slot * kStreamWaves * nq * cstride,
-                                      smem + p.off_vst + (size_t)wave * (32 * (LPT * 16 + 32)), nU, n2, row0, R, nq,
+                                      smem + p.off_vst + (size_t)wave * (32 * (D * 2 + 32)), nU, n2, row0, R, nq,
                                       qscale, lane, wave);
             else
                 stream_valu<KVT, NQ, LPT>(p, lists + (size_t)slot * p.max_entries + lo, qsts + (size_t)slot * nq * D,
@@ -1349,7 +1404,9 @@ hipError_t launch_attn_mfma(const AttnParams& p, int lpt, hipStream_t s) {
 #ifndef SPFA_EXPLORE
         case 4: return launch_attn_one<KVT, 16, 4, true>(p, s);
         case 8: return launch_attn_one<KVT, 16, 8, true>(p, s);
-        case 32: return launch_attn_one<KVT, 16, 32, true>(p, s);
+        case 32:
+            if constexpr (sizeof(KVT) == 2) return launch_attn_one<KVT, 16, 32, true>(p, s);
+            break;
 #endif
         case 16: return launch_attn_one<KVT, 16, 16, true>(p, s);
     }
@@ -1365,34 +1422,48 @@ int device_cu_count() {
     return n;
 }
 
-bool attention_uses_mfma(int rows_per_pass, int kv_dtype) { return rows_per_pass > 1 && kv_dtype != kI8; }
+// int8 KV with 512-byte head rows would need 128 accumulator registers for O^T: that shape stays on the VALU form.
+bool attention_uses_mfma(int rows_per_pass, int kv_dtype, int D) {
+    return rows_per_pass > 1 && !(kv_dtype == kI8 && D > 256);
+}
 
-int attention_rows_per_pass(int G, int kv_dtype) {
+int attention_rows_per_pass(int G, int kv_dtype, int D) {
     if (G <= 1) return 1;
-    if (kv_dtype == kI8) return 4;   // VALU streamer: int8 rows cost 16 accumulators each
-    return G < 16 ? G : 16;          // MFMA streamer: up to 16 columns
+    if (kv_dtype == kI8 && D > 256) return 4;   // VALU streamer: int8 rows cost 16 accumulators each
+    return G < 16 ? G : 16;                     // MFMA streamer: up to 16 columns
 }
 
 hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
     const int nq = p.rows_per_pass;
     const int esize = (p.kv_dtype == kI8) ? 1 : 2;
     const int lpt = p.D * esize / 16;
-    if (attention_uses_mfma(nq, p.kv_dtype)) {
+    if (attention_uses_mfma(nq, p.kv_dtype, p.D)) {
         if (nq > 16) return hipErrorInvalidValue;
 #ifdef SPFA_EXPLORE
         if (p.kv_dtype == kF16) return launch_attn_mfma<_Float16>(p, lpt, s);
+#ifdef SPFA_EXPLORE_I8
+        if (p.kv_dtype == kI8 && lpt == 8) return launch_attn_one<int8_t, 16, 8, true>(p, s);
+#endif
         return hipErrorInvalidValue;
 #else
-        return p.kv_dtype == kBF16 ? launch_attn_mfma<__bf16>(p, lpt, s) : launch_attn_mfma<_Float16>(p, lpt, s);
+        switch (p.kv_dtype) {
+            case kF16: return launch_attn_mfma<_Float16>(p, lpt, s);
+            case kBF16: return launch_attn_mfma<__bf16>(p, lpt, s);
+            case kI8: return launch_attn_mfma<int8_t>(p, lpt, s);
+        }
+        return hipErrorInvalidValue;
 #endif
     }
     switch (p.kv_dtype) {
         case kF16: if (nq == 1) return launch_attn_valu<_Float16, 1>(p, lpt, s); break;
+#ifdef SPFA_EXPLORE_I8
+        case kI8: if (nq == 1 && lpt == 8) return launch_attn_one<int8_t, 1, 8, false>(p, s); break;
+#endif
 #ifndef SPFA_EXPLORE
         case kBF16: if (nq == 1) return launch_attn_valu<__bf16, 1>(p, lpt, s); break;
         case kI8:
             if (nq == 1) return launch_attn_valu<int8_t, 1>(p, lpt, s);
-            if (nq == 4) return launch_attn_valu<int8_t, 4>(p, lpt, s);
+            if (nq == 4 && lpt == 32) return launch_attn_one<int8_t, 4, 32, false>(p, s);
             break;
 #endif
     }

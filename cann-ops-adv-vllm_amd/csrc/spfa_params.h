@@ -101,7 +101,7 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t s);
 int device_cu_count();
 // Number of q heads of a group one pass over the K/V pages serves, and whether that pass runs on the MFMA streamer
 // (which stages V tiles in LDS: 4 waves x 32 rows x (2 D + 32) bytes at off_vst).
-int attention_rows_per_pass(int G, int kv_dtype);
-bool attention_uses_mfma(int rows_per_pass, int kv_dtype);
+int attention_rows_per_pass(int G, int kv_dtype, int D);
+bool attention_uses_mfma(int rows_per_pass, int kv_dtype, int D);
 
 }  // namespace spfa

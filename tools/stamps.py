@@ -24,7 +24,8 @@ dbg = torch.zeros((1024, 16, 16), dtype=torch.int64, device=dev)
 _abi.lib.spfaSetDebugBuffer.argtypes = [ctypes.c_void_p]
 _abi.lib.spfaSetDebugBuffer(dbg.data_ptr())
 plan = custom_ops.PreparedFusion(wl["q"], wl["key"], wl["val"], wl["table"], wl["l1"], wl["block_ids"], wl["seq"],
-                                 pos, plen, pmax, Hq, D ** -0.5, Hkv, bs, k=a.topk)
+                                 pos, plen, pmax, Hq, D ** -0.5, Hkv, bs, k=a.topk, antiquant_scale=wl["a_scale"],
+                                 antiquant_offset=wl["a_off"])
 import numpy as np
 import time
 
@@ -73,6 +74,13 @@ print(f"prologue: start-spread(p50/max)={np.median(row[ok, 11] - t_first):.0f}/{
       f"end-start={np.median(row[ok, 14] - row[ok, 11]):.0f}")
 print("workgroup durations (ticks from its own start): " +
       " ".join(f"p{q}={np.percentile(ends, q):.0f}" for q in (0, 10, 50, 90, 100)))
+idx = np.nonzero(ok)[0]
+print("duration by blockIdx % 8 (mean, min, max): " + " | ".join(
+    f"{c}: {ends[idx % 8 == c].mean():.0f} {ends[idx % 8 == c].min():.0f} {ends[idx % 8 == c].max():.0f}" for c in range(8)))
+half = len(idx) // 2
+print(f"first half of the grid mean {ends[idx < half].mean():.0f}, second half {ends[idx >= half].mean():.0f}")
+per_item = d[:, 1:5, 9] - d[:, 1:5, 8]
+print("stream ticks by item position (median): " + " ".join(f"{np.median(per_item[ok, j][per_item[ok, j] > 0]):.0f}" for j in range(4)))
 n_items = (d[:, :, 8] > 0).sum(axis=1)[ok]
 print("items per workgroup: " + " ".join(f"{k}:{int((n_items == k).sum())}" for k in sorted(set(n_items.tolist()))))
 names = {(0, 1): "fetch", (1, 2): "score", (2, 3): "topk", (3, 4): "select", (4, 5): "union", (5, 6): "qstage"}
