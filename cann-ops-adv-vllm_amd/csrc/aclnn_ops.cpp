@@ -40,7 +40,7 @@ struct aclOpExecutor {
     std::vector<long long> act_seq;   // host copy of actualSeqLengths, expanded to B values
     // workspace layout of the two attention ops: [work counters | split arrival counters] (zeroed per launch),
     // split states, per-batch actualSeqLengths
-    uint64_t ws_zero_bytes = 0, ws_parts_off = 0, ws_lengths_off = 0;
+    uint64_t ws_zero_bytes = 0, ws_parts_off = 0, ws_lengths_off = 0, ws_boards_off = 0, ws_tail_off = 0;
     uint64_t ws_bytes = 0;
 };
 
@@ -51,6 +51,7 @@ thread_local int64_t g_topk = 64;
 thread_local int g_sink_recent = 0;
 thread_local int g_page_cap = 0;
 thread_local int g_max_split = 16;
+thread_local int g_tail_sharing = 1;
 thread_local int64_t g_page_size = 128;   // PAGESIZE of cent_select.cpp:17 / select_position.cpp:112
 thread_local const long long* g_act_seq_dev = nullptr;   // one-shot, consumed by the next attention plan
 thread_local int64_t g_act_seq_dev_n = 0;
@@ -253,6 +254,7 @@ aclnnStatus spfaSetMaxSplit(int64_t max_split) {
     g_max_split = (int)max_split;
     return ACLNN_SUCCESS;
 }
+aclnnStatus spfaSetTailSharing(int enable) { g_tail_sharing = enable ? 1 : 0; return ACLNN_SUCCESS; }
 aclnnStatus spfaSetPageSize(int64_t page_size) {
     if (page_size < 1 || page_size > 512) return fail(ACLNN_ERR_PARAM_INVALID, "page size %lld out of [1, 512]", (long long)page_size);
     g_page_size = page_size;
@@ -567,7 +569,7 @@ static size_t carve_lds(spfa::AttnParams& p, size_t nq) {
     const bool mfma = spfa::attention_uses_mfma((int)nq, p.kv_dtype, p.D);
     if (!mfma) off += align16((size_t)2 * nq * p.D * 4);                   // pre-scaled q rows (VALU streamer)
     p.off_hdr = (int)off;
-    off += 2 * 32 + 16;                                                    // two item headers + selector team words
+    off += 2 * 48 + 16;                                                    // two item headers + 4 workgroup words
     p.off_vst = (int)off;
     if (mfma) off += (size_t)4 * 32 * (p.D * 2 + 32);                      // V tile images of the 4 streamer waves
     return off;
@@ -606,10 +608,24 @@ static void plan_workspace(aclOpExecutor* e) {
         if (ns > p.max_entries) ns = p.max_entries;   // at least one page per share
         if (ns > 1) p.n_split = (int)ns;
     }
-    e->ws_zero_bytes = kCounterBytes + (p.n_split > 1 ? up256((uint64_t)items * 4) : 0);
+    // Sharing of every workgroup's last item (launches without a split): one board + data area per resident
+    // workgroup (at most two per CU): header, page list, q rows of the VALU streamer, 17 states.
+    // The protocol costs about 10 us per workgroup (claims, one more state to merge); it pays when a workgroup has
+    // several items to be out of step by, or long ones.
+    const bool worth = items >= 6ll * n_cu || (items > n_cu && p.max_entries >= 512);
+    p.tail_on = (g_tail_sharing && p.n_split == 1 && n_cu > 0 && worth) ? 1 : 0;
+    const uint64_t n_boards = p.tail_on ? 2ull * n_cu : 0;
+    const bool mfma = spfa::attention_uses_mfma(p.rows_per_pass, p.kv_dtype, p.D);
+    const uint64_t state_bytes = (uint64_t)p.rows_per_pass * (p.D + 2) * 4;
+    p.tail_chunks = p.rows_per_pass == 1 ? 32 : 16;   // one state per chunk + the owner's: keep the wide ones fewer
+    p.tail_stride = (long long)up256(32 + (uint64_t)p.max_entries * 8 + (mfma ? 0 : (uint64_t)p.rows_per_pass * p.D * 4) + 16 +
+                                     (uint64_t)(p.tail_chunks + 1) * state_bytes);
+    e->ws_boards_off = kCounterBytes + (p.n_split > 1 ? up256((uint64_t)items * 4) : 0);
+    e->ws_zero_bytes = e->ws_boards_off + up256(n_boards * 16);
     e->ws_parts_off = e->ws_zero_bytes;
-    const uint64_t parts = p.n_split > 1 ? up256((uint64_t)items * p.n_split * p.rows_per_pass * (p.D + 2) * 4) : 0;
-    e->ws_lengths_off = e->ws_parts_off + parts;
+    const uint64_t parts = p.n_split > 1 ? up256((uint64_t)items * p.n_split * state_bytes) : 0;
+    e->ws_tail_off = e->ws_parts_off + parts;
+    e->ws_lengths_off = e->ws_tail_off + n_boards * (uint64_t)p.tail_stride;
     e->ws_bytes = e->ws_lengths_off + (e->act_seq.empty() ? 0 : up256((uint64_t)p.B * 8));
 }
 
@@ -618,6 +634,8 @@ static hipError_t bind_workspace(const aclOpExecutor* e, spfa::AttnParams& p, vo
     p.counters = (unsigned*)workspace;
     p.split_done = (unsigned*)((char*)workspace + kCounterBytes);
     p.split_partials = (float*)((char*)workspace + e->ws_parts_off);
+    p.tail_boards = (char*)workspace + e->ws_boards_off;
+    p.tail_data = (char*)workspace + e->ws_tail_off;
     return hipMemsetAsync(workspace, 0, e->ws_zero_bytes, stream);
 }
 

@@ -502,14 +502,15 @@ struct PageEntry {            // 8 bytes in LDS
     unsigned short valid;     // attended tokens of the page (<= 512)
     unsigned short mask;      // bit g: head g of the pass attends this page (<= 16 heads per pass)
 };
-struct ItemHdr {              // 32 bytes in LDS
+struct ItemHdr {              // 40 bytes in LDS (a 48-byte slot)
     int item;                 // < 0: no more work
     int nU;                   // pages to stream: list[lo .. lo + nU)
     int b, n2;
     int row0;                 // first output row (b * Hq + head) of the pass
     int R;                    // q heads in the pass
     int lo;                   // first list entry of this workgroup's share (page-list split, else 0)
-    int pad;
+    int next;                 // the item this workgroup handles after this one (claimed one item ahead), < 0: none
+    int pc, nch;              // > 0: the workgroup's last item, shared in nch chunks of pc pages (see TailBoard)
 };
 
 template <typename KVT> struct KvTraits;
@@ -564,6 +565,9 @@ __device__ __forceinline__ void merge_state(float& m, float& l, float* o, int n,
 #ifndef SPFA_MINWAVES_N
 #define SPFA_MINWAVES_N 2    // launch-bounds waves per SIMD of the 2..4-q-head kernels
 #endif
+#ifndef SPFA_TAIL_MIN_PAGES
+#define SPFA_TAIL_MIN_PAGES 4 // MFMA streamer: fewest pages per chunk of a shared last item
+#endif
 #ifndef SPFA_MFMA_PREFETCH
 #define SPFA_MFMA_PREFETCH 1 // MFMA streamer: issue the next tile's loads before computing the current one
 #endif
@@ -613,13 +617,91 @@ __device__ __forceinline__ int fetch_item(unsigned* counters, int xcd, int total
 }
 
 // ------------------------------------------------------------------------------------------------
+// Sharing the last item of a workgroup.
+//
+// The items of a launch are equal-sized only on paper: XCDs run a few percent apart and real page lists differ in
+// length, and because the next item is claimed one item ahead nothing is left to steal when the fast workgroups run
+// dry.  So the LAST item of every workgroup is not streamed by static striding but in chunks of a few pages claimed
+// from a word in global memory: the owner's waves claim chunks from the front, workgroups that have finished their
+// own work claim from the back (they read the page list, which the owner published next to the word).  Every party
+// leaves an un-normalised state in the workspace and adds its chunk count to an arrival counter; the party that
+// completes the count merges the states and stores the output rows.  Nobody ever waits for anybody.
+// ------------------------------------------------------------------------------------------------
+struct TailBoard {           // 16 bytes per workgroup, zeroed before every launch
+    unsigned state;          // front (chunks claimed by the owner) | back << 16 (chunks below `back` are unclaimed)
+    unsigned pad;
+    unsigned long long done; // low word: chunks accounted for, + 1 for the owner's arrival; high word: bit c set when
+                             // a helper party left its state in slot 1 + c (c = the lowest chunk it took)
+};
+struct TailHdr {             // 32 bytes at the start of a board's data area, written before the board is offered
+    int nU, pc, nch;         // list length, pages per chunk, chunks
+    int n2, row0, R, b, pad;
+};
+constexpr int kHdrSlot = 48;                        // bytes per ItemHdr slot in LDS
+constexpr int kTailChunksMax = 32;                  // chunks per shared item (AttnParams::tail_chunks <= this)
+
+// Data that one workgroup hands to another inside a launch is written and read with agent-scope accesses, which go
+// past the non-coherent cache levels, and the writer waits for its stores before it signals with an atomic.  No
+// release/acquire fence is used: on this part a fence writes back / invalidates a whole L2, and hundreds of them per
+// XCD while the other workgroups still stream K/V cost more than the sharing saves.
+template <typename T>
+__device__ __forceinline__ void st_agent(T* ptr, T v) { __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename T>
+__device__ __forceinline__ T ld_agent(const T* ptr) {
+    return __hip_atomic_load(const_cast<T*>(ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void wait_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// Page cursor of one streamer wave: static striding (wave, wave + 4, ...) or chunk claims from a board.
+struct PageCursor {
+    unsigned* state;   // board word (modes 1, 2)
+    int mode;          // 0: static, 1: owner (front), 2: helper (back)
+    int pc, nch, nU;
+    int n, n_end, chunks, first;   // first: lowest chunk claimed
+    __device__ __forceinline__ void init(int mode_, unsigned* state_, int pc_, int nch_, int nU_, int wave) {
+        mode = mode_; state = state_; pc = pc_; nch = nch_; nU = nU_;
+        n = mode_ == 0 ? wave - kStreamWaves : 0; n_end = 0; chunks = 0; first = 1 << 20;
+    }
+    __device__ __forceinline__ int claim(int lane) {
+        int c = -1;
+        if (lane == 0) {
+            if (mode == 1) {
+                const unsigned old = atomicAdd(state, 1u);
+                const int f = (int)(old & 0xffffu), bk = (int)(old >> 16);
+                if (f < bk && f < nch) c = f;
+            } else {
+                for (int tries = 0; tries < 16; ++tries) {
+                    const unsigned old = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int f = (int)(old & 0xffffu), bk = (int)(old >> 16);
+                    if (bk <= f || bk > nch) break;
+                    if (atomicCAS(state, old, old - 0x10000u) == old) { c = bk - 1; break; }
+                }
+            }
+        }
+        return __builtin_amdgcn_readfirstlane(c);
+    }
+    // advance to the next page of this wave; false when there is none
+    __device__ __forceinline__ bool next(int lane) {
+        if (mode == 0) { n += kStreamWaves; return n < nU; }
+        if (++n < n_end) return true;
+        const int c = claim(lane);
+        if (c < 0) return false;
+        ++chunks;
+        first = min(first, c);
+        n = c * pc;
+        n_end = min(nU, n + pc);
+        return n < n_end;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
 // Streamer, VALU form (one q head per pass, and int8 KV): K/V pages of one item -> this wave's partial
 // softmax state in LDS.  list / qst / comb are the item's page list, pre-scaled q rows [NQ][D] and the
 // [4 waves][NQ][D + 2] state area.
 // ------------------------------------------------------------------------------------------------
 template <typename KVT, int NQ, int LPT>
 __device__ __forceinline__ void stream_valu(const AttnParams& p, const PageEntry* list, const float* qst, float* comb,
-                                            int nU, int n2, int lane, int wave) {
+                                            PageCursor& cur, int n2, int lane, int wave) {
     constexpr int EPL = KvTraits<KVT>::EPL;     // elements per 16-byte lane load
     constexpr int TPL = 64 / LPT;               // tokens per wave load
     constexpr int LG = (NQ * EPL <= 16) ? SPFA_LG1 : ((NQ * EPL <= 32) ? SPFA_LGN : 2);   // wave loads of K (and V) per step
@@ -656,7 +738,8 @@ __device__ __forceinline__ void stream_valu(const AttnParams& p, const PageEntry
     // bit pattern in a dead V row would otherwise poison 0 * v).
     const int lane_off = grp * (int)p.tok_stride + sub * 16;
     const int row_bytes = D * (int)sizeof(KVT);
-    for (int n = wave; n < nU; n += kStreamWaves) {
+    while (cur.next(lane)) {
+        const int n = cur.n;
         const int phys = __builtin_amdgcn_readfirstlane(list[n].phys);
         const int valid = __builtin_amdgcn_readfirstlane(list[n].valid);
         const unsigned mask = __builtin_amdgcn_readfirstlane((unsigned)list[n].mask);
@@ -770,7 +853,7 @@ __device__ __forceinline__ void stream_valu(const AttnParams& p, const PageEntry
 // ------------------------------------------------------------------------------------------------
 template <typename KVT, int LPT>
 __device__ __forceinline__ void stream_mfma(const AttnParams& p, const PageEntry* list, float* comb, char* vst,
-                                            int nU, int n2, long long row0, int R, int nq, float qscale,
+                                            PageCursor& cur, int n2, long long row0, int R, int nq, float qscale,
                                             int lane, int wave) {
     constexpr bool BF16 = __is_same(KVT, __bf16);
     constexpr bool I8 = sizeof(KVT) == 1;
@@ -951,11 +1034,12 @@ __device__ __forceinline__ void stream_mfma(const AttnParams& p, const PageEntry
     };
 
     const int row_bytes = D * ES;
-    // page cursor of this wave: pages wave, wave + 4, ... of the list, 32-token tiles inside a page
-    int n = wave, t0 = 0, valid = 0;
+    // pages come from the cursor (static striding or chunk claims), 32-token tiles inside a page
+    int t0 = 0, valid = 0;
     bool att = false;
     __amdgpu_buffer_rsrc_t rk, rv;
     auto open_page = [&]() {
+        const int n = cur.n;
         const int phys = __builtin_amdgcn_readfirstlane(list[n].phys);
         valid = __builtin_amdgcn_readfirstlane((int)list[n].valid);
         const unsigned mask = __builtin_amdgcn_readfirstlane((unsigned)list[n].mask);
@@ -965,26 +1049,26 @@ __device__ __forceinline__ void stream_mfma(const AttnParams& p, const PageEntry
         rk = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.kcache + off), 0, range, 0x00020000);
         rv = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.vcache + off), 0, range, 0x00020000);
     };
-    if (n < nU) {
+    if (cur.next(lane)) {
         open_page();
-        Tile cur;
-        issue(cur, rk, rv, 0);
+        Tile cur_t;
+        issue(cur_t, rk, rv, 0);
         while (true) {
             const int c_t0 = t0, c_valid = valid;
             const bool c_att = att;
+            bool more = true;
             t0 += 32;
-            if (t0 >= valid) { n += kStreamWaves; t0 = 0; if (n < nU) open_page(); }
-            const bool more = n < nU;
+            if (t0 >= valid) { t0 = 0; more = cur.next(lane); if (more) open_page(); }
             if constexpr (PREFETCH) {
                 Tile nxt;
                 if (more) issue(nxt, rk, rv, t0);
-                compute(cur, c_t0, c_valid, c_att);
+                compute(cur_t, c_t0, c_valid, c_att);
                 if (!more) break;
-                cur = nxt;
+                cur_t = nxt;
             } else {
-                compute(cur, c_t0, c_valid, c_att);
+                compute(cur_t, c_t0, c_valid, c_att);
                 if (!more) break;
-                issue(cur, rk, rv, t0);
+                issue(cur_t, rk, rv, t0);
             }
         }
     }
@@ -1032,7 +1116,15 @@ void attn_kernel(const AttnParams p) {
     float* combs = (float*)(smem + p.off_comb);                                   // [2][4][nq][D+2]
     float* qsts = (float*)(smem + p.off_qst);                                     // [2][nq][D]
     ItemHdr* hdrs = (ItemHdr*)(smem + p.off_hdr);                                 // [2]
-    int* team = (int*)(smem + p.off_hdr + 2 * sizeof(ItemHdr));                   // [0] sync counter, [1] item
+    int* team = (int*)(smem + p.off_hdr + 2 * kHdrSlot);   // [0] selector team counter, [1] lowest chunk, [2] flag, [3] chunks
+    auto hdr_at = [&](int slot) { return (ItemHdr*)((char*)hdrs + slot * kHdrSlot); };
+    TailBoard* boards = (TailBoard*)p.tail_boards;
+    TailBoard* my_board = boards + blockIdx.x;
+    auto board_data = [&](int v) { return p.tail_data + (size_t)v * p.tail_stride; };
+    // data area of a board: TailHdr | page list [max_entries] | pre-scaled q rows [nq][D] | states [1 + tail_chunks][nq][D+2]
+    const size_t tail_list_off = sizeof(TailHdr);
+    const size_t tail_qst_off = tail_list_off + (size_t)p.max_entries * sizeof(PageEntry);
+    const size_t tail_part_off = (tail_qst_off + (MFMA ? 0 : (size_t)nq * D * 4) + 15) & ~(size_t)15;
     int team_epoch = 0;
     // Meeting point of the selector team (not of the workgroup): a counter in LDS.  Every team wave passes through
     // the same sequence of calls, so the spin always ends; LDS operations of a wave execute in order, which makes
@@ -1095,21 +1187,10 @@ void attn_kernel(const AttnParams p) {
     // item < 0: fetch the next one; stage: 0 nothing done yet, 1 the keys of this item are already in LDS,
     // 2 the rows' page lists are done as well (bitmaps in pbits_all, lengths in row_lens)
     auto build = [&](int slot, int item, int stage) {
-        ItemHdr* hdr = hdrs + slot;
+        ItemHdr* hdr = hdr_at(slot);
         PageEntry* list = lists + (size_t)slot * p.max_entries;
         float* qst = qsts + (size_t)slot * nq * D;
         SPFA_STAMP(0);
-        if constexpr (SW > 1) {
-            if (sidx == 0) {
-                if (item < 0) item = fetch_item(p.counters, xcd, total, (int)gridDim.x, lane);
-                if (lane == 0) team[1] = item;
-            }
-            team_sync();
-            item = __builtin_amdgcn_readfirstlane(team[1]);
-        } else {
-            if (item < 0) item = fetch_item(p.counters, xcd, total, (int)gridDim.x, lane);
-        }
-        SPFA_STAMP(1);
         if (item < 0) {
             if (lane == 0 && sidx == 0) hdr->item = -1;
             return;
@@ -1201,8 +1282,37 @@ void attn_kernel(const AttnParams p) {
             qst[t] = v;
         }
         SPFA_STAMP(6);
+        // claim the item after this one now: whether this is the workgroup's last item must be known before it is
+        // streamed
+        const int nxt = total > (int)gridDim.x ? fetch_item(p.counters, xcd, total, (int)gridDim.x, lane) : -1;
+        SPFA_STAMP(1);
+        nU = min(nU, p.max_entries);
+        int pc = 0, nch = 0;
+        if (p.tail_on && nxt < 0 && nU > 0) {
+            // last item: publish the list (and the q rows of the VALU streamer) and offer it in chunks
+            // a claim drains the wave's loads in flight: keep the chunks of the wide (MFMA) streamer a few pages long
+            pc = max((nU + p.tail_chunks - 1) / p.tail_chunks, MFMA ? SPFA_TAIL_MIN_PAGES : 1);
+            nch = (nU + pc - 1) / pc;
+            char* bd = board_data((int)blockIdx.x);
+            unsigned long long* glist = (unsigned long long*)(bd + tail_list_off);
+            wave_lds_sync();
+            for (int i = lane; i < nU; i += 64) st_agent(glist + i, ((const unsigned long long*)list)[i]);
+            if (!MFMA) {
+                float* gq = (float*)(bd + tail_qst_off);
+                for (int t = lane; t < nq * D; t += 64) st_agent(gq + t, qst[t]);
+            }
+            if (lane < 8) {
+                const int vals[8] = {nU, pc, nch, n2, (int)row0, R, b, 0};   // TailHdr
+                int mine = 0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) mine = (lane == i) ? vals[i] : mine;
+                st_agent((int*)bd + lane, mine);
+            }
+            if (lane == 0) team[3] = 0;
+            wait_stores();   // the data is in memory before the offer
+            if (lane == 0) atomicExch(&my_board->state, (unsigned)nch << 16);
+        }
         if (lane == 0) {
-            nU = min(nU, p.max_entries);
             const int share = (nU + NS - 1) / NS;
             const int lo = min(nU, ctx.split * share);
             hdr->item = item;
@@ -1212,6 +1322,9 @@ void attn_kernel(const AttnParams p) {
             hdr->n2 = n2;
             hdr->row0 = (int)row0;
             hdr->R = R;
+            hdr->next = nxt;
+            hdr->pc = pc;
+            hdr->nch = nch;
         }
     };
 
@@ -1228,7 +1341,8 @@ void attn_kernel(const AttnParams p) {
         else if (p.out_dtype == kBF16) ((__bf16*)p.out)[oi] = (__bf16)r;   // round to nearest even (…Us2.h:3476-3477)
         else ((_Float16*)p.out)[oi] = (_Float16)r;
     };
-    auto finalize = [&](int slot, int row0, int R, int n2) {
+    // dst == nullptr: normalise and store the output rows; else leave the merged, un-normalised state [nq][D + 2] there
+    auto finalize = [&](int slot, int row0, int R, int n2, float* dst_state) {
         const float* comb = combs + (size_t)slot * kStreamWaves * nq * cstride;
         for (int t = threadIdx.x; t < R * D; t += kStreamWaves * 64) {
             const int g = t / D, d = t - g * D;
@@ -1241,13 +1355,54 @@ void attn_kernel(const AttnParams p) {
                 acc += src[d] * c;
                 lt += src[D + 1] * c;
             }
-            if (NS == 1) {
+            if (dst_state == nullptr) {
                 store_out((long long)row0 + g, d, n2, acc, lt);
-            } else {   // this workgroup's share of the item: un-normalised state [nq][D + 2] of unit blockIdx.x
-                float* dst = p.split_partials + ((size_t)blockIdx.x * nq + g) * cstride;
-                dst[d] = acc;
-                if (d == 0) { dst[D] = mt; dst[D + 1] = lt; }
+            } else {
+                float* dst = dst_state + (size_t)g * cstride;
+                st_agent(dst + d, acc);
+                if (d == 0) { st_agent(dst + D, mt); st_agent(dst + D + 1, lt); }
             }
+        }
+    };
+    // merge the un-normalised states [..][nq][D + 2] whose bit is set in `which` and store the output rows (all waves
+    // take part)
+    auto merge_states = [&](const float* parts, unsigned long long which, long long row0, int R, int n2) {
+        for (int t = threadIdx.x; t < R * D; t += WAVES * 64) {
+            const int g = t / D, d = t - g * D;
+            float mt = kNegBig;
+            for (unsigned long long w = which; w; w &= w - 1) {
+                const int u = __ffsll((long long)w) - 1;
+                mt = fmaxf(mt, ld_agent(parts + ((size_t)u * nq + g) * cstride + D));
+            }
+            float acc = 0.f, lt = 0.f;
+            for (unsigned long long w = which; w; w &= w - 1) {
+                const int u = __ffsll((long long)w) - 1;
+                const float* src = parts + ((size_t)u * nq + g) * cstride;
+                const float cf = fast_exp2(ld_agent(src + D) - mt);
+                acc += ld_agent(src + d) * cf;
+                lt += ld_agent(src + D + 1) * cf;
+            }
+            store_out(row0 + g, d, n2, acc, lt);
+        }
+    };
+    // where the state of item `slot` goes: the output (nullptr), this unit's split slot, or slot 0 of the own board
+    auto state_target = [&](bool shared) -> float* {
+        if (NS > 1) return p.split_partials + (size_t)blockIdx.x * nq * cstride;
+        if (shared) return (float*)(board_data((int)blockIdx.x) + tail_part_off);
+        return nullptr;
+    };
+    auto run_stream = [&](const PageEntry* list, const float* qst, int slot, PageCursor& cur, int n2, long long row0,
+                          int R) {
+        if constexpr (MFMA)
+            stream_mfma<KVT, LPT>(p, list, combs + (size_t)slot * kStreamWaves * nq * cstride,
+                                  smem + p.off_vst + (size_t)wave * (32 * (D * 2 + 32)), cur, n2, row0, R, nq, qscale,
+                                  lane, wave);
+        else
+            stream_valu<KVT, NQ, LPT>(p, list, qst, combs + (size_t)slot * kStreamWaves * nq * cstride, cur, n2, lane,
+                                      wave);
+        if (cur.mode != 0 && lane == 0 && cur.chunks > 0) {
+            atomicAdd(&team[3], cur.chunks);
+            atomicMin(&team[1], cur.first);
         }
     };
 
@@ -1285,31 +1440,30 @@ void attn_kernel(const AttnParams p) {
     stamp_item = 1;
 #endif
     int prev_row0 = 0, prev_R = 0, prev_n2 = 0;
-    bool have_prev = false;
+    bool have_prev = false, prev_shared = false;
 #if SPFA_PRIO
     // the streamers' issue slots come first; the selector wave works in the gaps they leave
     if (!selector) __builtin_amdgcn_s_setprio(SPFA_PRIO);
 #endif
     while (true) {
-        const int item = __builtin_amdgcn_readfirstlane(hdrs[slot].item);
-        const int nU = __builtin_amdgcn_readfirstlane(hdrs[slot].nU);
-        const int lo = __builtin_amdgcn_readfirstlane(hdrs[slot].lo);
-        const int n2 = __builtin_amdgcn_readfirstlane(hdrs[slot].n2);
-        const int row0 = __builtin_amdgcn_readfirstlane(hdrs[slot].row0);
-        const int R = __builtin_amdgcn_readfirstlane(hdrs[slot].R);
-        if (have_prev && !selector) finalize(slot ^ 1, prev_row0, prev_R, prev_n2);
+        const ItemHdr* h = hdr_at(slot);
+        const int item = __builtin_amdgcn_readfirstlane(h->item);
+        const int nU = __builtin_amdgcn_readfirstlane(h->nU);
+        const int lo = __builtin_amdgcn_readfirstlane(h->lo);
+        const int n2 = __builtin_amdgcn_readfirstlane(h->n2);
+        const int row0 = __builtin_amdgcn_readfirstlane(h->row0);
+        const int R = __builtin_amdgcn_readfirstlane(h->R);
+        const int next = __builtin_amdgcn_readfirstlane(h->next);
+        const int pc = __builtin_amdgcn_readfirstlane(h->pc);
+        const int nch = __builtin_amdgcn_readfirstlane(h->nch);
+        if (have_prev && !selector) finalize(slot ^ 1, prev_row0, prev_R, prev_n2, state_target(prev_shared));
         if (item < 0) break;
-        if (selector) build(slot ^ 1, -1, 0);
+        if (selector) build(slot ^ 1, next, 0);
         else {
             if (wave == 0) SPFA_STAMP(8);
-            if constexpr (MFMA)
-                stream_mfma<KVT, LPT>(p, lists + (size_t)slot * p.max_entries + lo,
-                                      combs + (size_t)slot * kStreamWaves * nq * cstride,
-                                      smem + p.off_vst + (size_t)wave * (32 * (D * 2 + 32)), nU, n2, row0, R, nq,
-                                      qscale, lane, wave);
-            else
-                stream_valu<KVT, NQ, LPT>(p, lists + (size_t)slot * p.max_entries + lo, qsts + (size_t)slot * nq * D,
-                                          combs + (size_t)slot * kStreamWaves * nq * cstride, nU, n2, lane, wave);
+            PageCursor cur;
+            cur.init(nch > 0 ? 1 : 0, &my_board->state, pc, nch, nU, wave);
+            run_stream(lists + (size_t)slot * p.max_entries + lo, qsts + (size_t)slot * nq * D, slot, cur, n2, row0, R);
             if (wave == 0) SPFA_STAMP(9);
         }
         __syncthreads();
@@ -1317,36 +1471,136 @@ void attn_kernel(const AttnParams p) {
 #ifdef SPFA_STAMPS
         stamp_item = min(stamp_item + 1, 15);
 #endif
-        prev_row0 = row0; prev_R = R; prev_n2 = n2; have_prev = true;
+        prev_row0 = row0; prev_R = R; prev_n2 = n2; have_prev = true; prev_shared = nch > 0;
         slot ^= 1;
     }
     if (NS > 1) {
-        // One unit per workgroup (grid == units), its state is in global memory.  Publish it (release), count
-        // arrivals per item, and let the last workgroup of an item merge the NS states (acquire) into the output.
-        __threadfence();
+        // One unit per workgroup (grid == units), its state is in global memory (agent-scope stores, waited for), count
+        // arrivals per item, and let the last workgroup of an item merge the NS states into the output.
+        wait_stores();
         __syncthreads();
         const int item = (int)blockIdx.x / NS;
         if (threadIdx.x == 0) team[2] = (int)atomicAdd(p.split_done + item, 1u);
         __syncthreads();
         if (team[2] == NS - 1) {
-            __threadfence();
             const ItemCtx c = decode((int)blockIdx.x);
-            const float* parts = p.split_partials + (size_t)item * NS * nq * cstride;
-            for (int t = threadIdx.x; t < c.R * D; t += WAVES * 64) {
-                const int g = t / D, d = t - g * D;
-                float mt = kNegBig;
-                for (int u = 0; u < NS; ++u) mt = fmaxf(mt, parts[((size_t)u * nq + g) * cstride + D]);
-                float acc = 0.f, lt = 0.f;
-                for (int u = 0; u < NS; ++u) {
-                    const float* src = parts + ((size_t)u * nq + g) * cstride;
-                    const float cf = fast_exp2(src[D] - mt);
-                    acc += src[d] * cf;
-                    lt += src[D + 1] * cf;
+            merge_states(p.split_partials + (size_t)item * NS * nq * cstride, (1ull << NS) - 1ull, c.row0, c.R, c.n2);
+        }
+        return;
+    }
+    if (!p.tail_on) return;
+#ifdef SPFA_STAMPS
+    stamp_item = 15;
+    int dbg_passes = 0, dbg_chunks = 0;
+    if (wave == 0) SPFA_STAMP(0);
+#endif
+    // ---------------- the shared last item: arrive, then help the others ----------------
+    // A party adds its chunk count to the board's counter after its state is in memory; the owner adds one more,
+    // so the count is complete (chunks + 1) only when the owner has arrived too.  Whoever completes it merges the
+    // states.  States: slot 0 the owner's, slot 1 + c the helper party's whose lowest chunk was c.
+    auto arrive = [&](int v, int add, int slot_bit, const TailHdr& th) {
+        wait_stores();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned long long inc = (unsigned long long)add | (slot_bit >= 0 ? (1ull << (32 + slot_bit)) : 0ull);
+            const unsigned long long now = atomicAdd(&boards[v].done, inc) + inc;
+            const bool complete = (unsigned)(now & 0xffffffffull) == (unsigned)th.nch + 1u;
+            team[2] = complete ? 1 : 0;
+            team[1] = (int)(now >> 32);
+        }
+        __syncthreads();
+        if (team[2]) {
+            const unsigned long long which = 1ull | ((unsigned long long)(unsigned)team[1] << 1);
+            merge_states((const float*)(board_data(v) + tail_part_off), which, th.row0, th.R, th.n2);
+        }
+        __syncthreads();
+    };
+    if (prev_shared) {
+        TailHdr th;
+        th.nch = __builtin_amdgcn_readfirstlane(hdr_at(slot ^ 1)->nch);
+        th.row0 = prev_row0; th.R = prev_R; th.n2 = prev_n2;
+        const int own = team[3];
+        arrive((int)blockIdx.x, own + 1, -1, th);
+    }
+#ifdef SPFA_STAMPS
+    if (wave == 0) SPFA_STAMP(1);
+#endif
+    int empty_scans = 0;
+    for (int pass = 0; pass < 2 * (int)gridDim.x; ++pass) {
+#ifdef SPFA_STAMPS
+        dbg_passes = pass + 1;
+#endif
+        if (wave == 0) {
+            // Look at 64 boards (a different window per workgroup and pass; the whole grid once nothing turns up) and
+            // take one of those with the most unclaimed chunks, ties and near-ties broken per workgroup so that the
+            // helpers spread out instead of all descending on one board.
+            unsigned best = 0;
+            const unsigned salt = (blockIdx.x * 0x9E3779B1u) ^ ((unsigned)pass * 0x85EBCA6Bu);
+            const int rounds = empty_scans == 0 ? 1 : ((int)gridDim.x + 63) / 64;
+            for (int r = 0; r < rounds; ++r) {
+                const unsigned i = empty_scans == 0 ? (salt >> 8) + (unsigned)lane * 7u + 1u : (unsigned)(r * 64 + lane + 1);
+                const unsigned v = (blockIdx.x + i) % gridDim.x;
+                if (v != blockIdx.x) {
+                    const unsigned st = ld_agent(&boards[v].state);
+                    const int rem = (int)(st >> 16) - (int)(st & 0xffffu);
+                    if (rem > 0 && (st >> 16) <= (unsigned)kTailChunksMax)
+                        best = max(best, ((unsigned)((rem + 3) >> 2) << 26) | (((v * 0x9E3779B1u) ^ salt) >> 22 << 16) | v);
                 }
-                store_out(c.row0 + g, d, c.n2, acc, lt);
+            }
+            best = wave_max_u32(best);
+            if (lane == 0) {
+                team[2] = best ? (int)(best & 0xffffu) : -1;
+                team[3] = 0;
+                team[1] = 1 << 20;
             }
         }
+        __syncthreads();
+        const int v = team[2];
+        if (v < 0) {
+            if (empty_scans++ > 0) break;   // nothing in the window, then nothing anywhere
+            __syncthreads();
+            continue;
+        }
+        empty_scans = 0;
+        // the board's data was in memory before it was offered: copy it into this workgroup's LDS (slot 0)
+        const char* bd = board_data(v);
+        TailHdr th;
+        th.nU = ld_agent((const int*)bd + 0); th.pc = ld_agent((const int*)bd + 1); th.nch = ld_agent((const int*)bd + 2);
+        th.n2 = ld_agent((const int*)bd + 3); th.row0 = ld_agent((const int*)bd + 4); th.R = ld_agent((const int*)bd + 5);
+        th.b = 0; th.pad = 0;
+        th.nU = min(max(th.nU, 0), p.max_entries);
+        for (int i = threadIdx.x; i < th.nU; i += WAVES * 64)
+            ((unsigned long long*)lists)[i] = ld_agent((const unsigned long long*)(bd + tail_list_off) + i);
+        if (!MFMA)
+            for (int t = threadIdx.x; t < nq * D; t += WAVES * 64) qsts[t] = ld_agent((const float*)(bd + tail_qst_off) + t);
+        __syncthreads();   // the copies are complete, and everybody has read team[2] before it is reused
+        if (!selector) {
+            PageCursor cur;
+            cur.init(2, &boards[v].state, th.pc, th.nch, th.nU, wave);
+            run_stream(lists, qsts, 0, cur, th.n2, th.row0, th.R);
+        }
+        __syncthreads();
+        const int got = team[3];
+        const int first = team[1];
+#ifdef SPFA_STAMPS
+        dbg_chunks += got;
+#endif
+        if (got > 0) {
+            if (!selector)
+                finalize(0, th.row0, th.R, th.n2,
+                         (float*)(board_data(v) + tail_part_off) + (size_t)(1 + first) * nq * cstride);
+            arrive(v, got, first, th);
+        }
+        __syncthreads();
     }
+#ifdef SPFA_STAMPS
+    if (wave == 0) SPFA_STAMP(2);
+    if (p.debug && threadIdx.x == 0) {
+        p.debug[((size_t)blockIdx.x * 16 + 15) * 16 + 3] = (unsigned long long)dbg_passes;
+        p.debug[((size_t)blockIdx.x * 16 + 15) * 16 + 4] = (unsigned long long)dbg_chunks;
+        p.debug[((size_t)blockIdx.x * 16 + 15) * 16 + 5] = (unsigned long long)(prev_shared ? team[3] + 1 : 0);
+    }
+#endif
 }
 
 template <typename KVT, int NQ, int LPT, bool MFMA>

@@ -85,6 +85,12 @@ struct AttnParams {
     unsigned* counters;            // 8 work counters (workspace), zeroed before every launch
     // page-list split for small batches: n_split workgroups per item (1: off)
     int n_split;
+    // sharing of every workgroup's last item (n_split == 1 only): boards and their data areas in the workspace
+    int tail_on;
+    int tail_chunks;               // chunks a shared item is cut into (<= 32)
+    void* tail_boards;             // [2 * #CU] 16-byte boards, zeroed before every launch
+    char* tail_data;               // [2 * #CU] data areas of tail_stride bytes
+    long long tail_stride;
     unsigned* split_done;          // [items] arrival counters (workspace), zeroed before every launch
     float* split_partials;         // [items * n_split][rows_per_pass][D + 2] un-normalised states (workspace)
     unsigned long long* debug;     // diagnostic builds only: [grid][16 items][16 stamps], else null

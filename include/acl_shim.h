@@ -98,6 +98,10 @@ SPFA_API aclnnStatus spfaSetPageCap(int enable);
  * to maxSplit workgroups and merge their states in the same launch; the reported workspace size grows by the
  * states.  1 turns the split off.  Default 16, range [1, 16]. */
 SPFA_API aclnnStatus spfaSetMaxSplit(int64_t maxSplit);
+/* Launches with several items per workgroup: the last item of every workgroup is streamed in chunks that
+ * workgroups which ran out of work may take over (states merged in the same launch; workspace grows by one data
+ * area per resident workgroup).  0 turns it off.  Default on. */
+SPFA_API aclnnStatus spfaSetTailSharing(int enable);
 /* page size of the two ops without a blockSize attribute (CentSelect, SelectPosition); the reference
  * compiles in 128 (cent_select.cpp:17, select_position.cpp:112).  Default 128. */
 SPFA_API aclnnStatus spfaSetPageSize(int64_t pageSize);

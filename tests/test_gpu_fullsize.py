@@ -115,20 +115,31 @@ def test_c3_f16_mha_full_size():
     check_selection_properties(a, wl, pos, plen, pmax)
     check_fused_equals_separate(a, wl, out, pos, plen, pmax)
     check_against_oracle(a, wl, out, pos, plen, pmax, [0, a.batch - 1])
-    # V -> 2V doubles the fp32 output exactly (power-of-two scaling commutes with every rounding on the way)
-    wl["val"].mul_(2)
-    out2, pos2, _, _ = run_fused(a, wl)
-    assert torch.equal(pos, pos2)
-    assert torch.equal(out2, out * 2)
-    # constant V: the output is that constant whatever was selected
+    # Sharing of the workgroups' last items makes the order of the partial sums depend on timing: the same launch
+    # repeated agrees to rounding, not bit for bit.  Without it the result is reproducible, and exact identities hold.
+    from custom_ops import _abi
+    again, _, _, _ = run_fused(a, wl)
+    assert float((again - out).abs().max()) <= 2e-6 * float(out.abs().max())
+    _abi.check(_abi.spfaSetTailSharing(0), "spfaSetTailSharing")
+    try:
+        det, dpos, _, _ = run_fused(a, wl)
+        det2, _, _, _ = run_fused(a, wl)
+        assert torch.equal(det, det2) and torch.equal(dpos, pos)
+        assert float((det - out).abs().max()) <= 2e-6 * float(out.abs().max())
+        # V -> 2V doubles the fp32 output exactly (power-of-two scaling commutes with every rounding on the way)
+        wl["val"].mul_(2)
+        out2, pos2, _, _ = run_fused(a, wl)
+        assert torch.equal(pos, pos2)
+        assert torch.equal(out2, det * 2)
+        # f16 output == the fp32 result rounded once
+        o16, _, _, _ = run_fused(a, wl, out_dtype=None)
+        assert o16.dtype == torch.float16 and torch.equal(o16, out2.to(torch.float16))
+    finally:
+        _abi.spfaSetTailSharing(1)
+    # constant V: the output is that constant whatever was selected and whoever streamed it
     wl["val"].fill_(0.375)
     out3, _, _, _ = run_fused(a, wl)
     assert float((out3 - 0.375).abs().max()) <= 5e-6
-    # f16 output == the fp32 result rounded once
-    wl["val"].uniform_(1e-3, 1.0)
-    o32, _, _, _ = run_fused(a, wl)
-    o16, _, _, _ = run_fused(a, wl, out_dtype=None)
-    assert o16.dtype == torch.float16 and torch.equal(o16, o32.to(torch.float16))
     del wl
     torch.cuda.empty_cache()
 

@@ -57,6 +57,11 @@ try:
         wl["q"], wl["key"], wl["val"], e, e, act, e, e, e, e, e, e, e, wl["table"], ei, pos, Hq, D ** -0.5, "BNSD", Hkv, bs, 1))
 except RuntimeError:
     d_attn = np.zeros((1, 16, 16), dtype="int64")
+_ok = d_attn[:, 1, 8] > 0
+if _ok.any():
+    _idx = np.nonzero(_ok)[0]
+    _dur = d_attn[:, :, 10].max(axis=1)[_ok] - d_attn[_ok, 1, 8]
+    print("attention only, duration by blockIdx % 8 (mean): " + " ".join(f"{c}:{_dur[_idx % 8 == c].mean():.0f}" for c in range(8)))
 for it in range(5):
     row = d_attn[:, it, :]
     ms = (row[:, 9] > 0) & (row[:, 8] > 0)
@@ -67,7 +72,7 @@ d = report("fused", plan.run)
 row = d[:, 0, :]
 ok = row[:, 11] > 0
 t_first = row[ok, 11].min()
-ends = d[:, :, 10].max(axis=1)[ok] - row[ok, 11]   # s_memtime bases differ between XCDs: only own-start deltas
+ends = d[:, :15, 10].max(axis=1)[ok] - row[ok, 11]   # s_memtime bases differ between XCDs: only own-start deltas
 print(f"prologue: start-spread(p50/max)={np.median(row[ok, 11] - t_first):.0f}/{(row[ok, 11] - t_first).max():.0f} "
       f"score={np.median(row[ok, 12] - row[ok, 11]):.0f} "
       f"rows={np.median((row[ok, 13] - row[ok, 12])[row[ok, 13] > 0]) if (row[ok, 13] > 0).any() else 0:.0f} "
@@ -81,7 +86,14 @@ half = len(idx) // 2
 print(f"first half of the grid mean {ends[idx < half].mean():.0f}, second half {ends[idx >= half].mean():.0f}")
 per_item = d[:, 1:5, 9] - d[:, 1:5, 8]
 print("stream ticks by item position (median): " + " ".join(f"{np.median(per_item[ok, j][per_item[ok, j] > 0]):.0f}" for j in range(4)))
-n_items = (d[:, :, 8] > 0).sum(axis=1)[ok]
+t15 = d[:, 15, :]
+if (t15[ok, 0] > 0).any():
+    print(f"tail: loop exit -> own arrival {np.median(t15[ok, 1] - t15[ok, 0]):.0f}, helping {np.median(t15[ok, 2] - t15[ok, 1]):.0f} "
+          f"(max {np.max(t15[ok, 2] - t15[ok, 1]):.0f}) ticks; passes p50/max {np.median(t15[ok, 3]):.0f}/{t15[ok, 3].max()}; "
+          f"chunks helped total {t15[ok, 4].sum()}, per wg max {t15[ok, 4].max()}")
+    print(f"tail: loop exit relative to own start p0/p50/p100: " + " ".join(f"{np.percentile(t15[ok, 0] - row[ok, 11], q):.0f}" for q in (0, 50, 100)))
+    print(f"tail: kernel end relative to own start p0/p50/p100: " + " ".join(f"{np.percentile(t15[ok, 2] - row[ok, 11], q):.0f}" for q in (0, 50, 100)))
+n_items = (d[:, 1:15, 8] > 0).sum(axis=1)[ok]
 print("items per workgroup: " + " ".join(f"{k}:{int((n_items == k).sum())}" for k in sorted(set(n_items.tolist()))))
 names = {(0, 1): "fetch", (1, 2): "score", (2, 3): "topk", (3, 4): "select", (4, 5): "union", (5, 6): "qstage"}
 for it in range(5):
