@@ -569,7 +569,8 @@ __device__ __forceinline__ void merge_state(float& m, float& l, float* o, int n,
 #define SPFA_TAIL_MIN_PAGES 4 // MFMA streamer: fewest pages per chunk of a shared last item
 #endif
 #ifndef SPFA_MFMA_PREFETCH
-#define SPFA_MFMA_PREFETCH 1 // MFMA streamer: issue the next tile's loads before computing the current one
+#define SPFA_MFMA_PREFETCH 0 // MFMA streamer: 1 = issue the next tile's loads before computing the current one.  Costs
+                             // 64 VGPRs, which pushes the selector's top-k keys into scratch: measured slower.
 #endif
 #ifndef SPFA_PRIO
 #define SPFA_PRIO 0          // wave priority of the streamer waves in the item loop (selector stays at 0)
@@ -601,19 +602,43 @@ constexpr int attn_threads(bool mfma) { return 64 * (kStreamWaves + sel_waves(mf
 // Pull the next work item.  Class c holds items c, c+8, ...; start with this XCD's class.
 // The first item of every workgroup is static (item = blockIdx.x, which is the (blockIdx.x / 8)-th item of
 // class blockIdx.x % 8), so the counters only hand out the items behind those.
-__device__ __forceinline__ int fetch_item(unsigned* counters, int xcd, int total, int grid, int lane) {
+// Classes are tried in the order xcd, xcd + 1, ... (from the t_first-th on).  One look at all eight counters tells
+// which classes still have items, so an exhausted queue costs one load instead of eight dependent atomics.
+__device__ __forceinline__ int fetch_item(unsigned* counters, int xcd, int total, int grid, int lane, int t_first = 0) {
+    const int c = (xcd + lane) & 7;
+    const int n_c = (total - c + 7) >> 3;      // items of class c
+    const int first = (grid - c + 7) >> 3;     // of which statically assigned
+    bool open = false;
+    if (lane >= t_first && lane < 8 && n_c > first)
+        open = __hip_atomic_load(&counters[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + (unsigned)first < (unsigned)n_c;
+    unsigned long long cand = __ballot(open);
     int item = -1;
-    if (lane == 0) {
-        for (int t = 0; t < 8 && item < 0; ++t) {
-            const int c = (xcd + t) & 7;
-            const int n_c = (total - c + 7) >> 3;      // items of class c
-            const int first = (grid - c + 7) >> 3;     // of which statically assigned
-            if (n_c <= first) continue;
-            const unsigned i = atomicAdd(&counters[c], 1u) + (unsigned)first;
-            if (i < (unsigned)n_c) item = c + 8 * (int)i;
-        }
+    while (cand && item < 0) {
+        const int t = __ffsll((long long)cand) - 1;
+        cand &= cand - 1;
+        const int ct = (xcd + t) & 7;
+        const int n_t = (total - ct + 7) >> 3, first_t = (grid - ct + 7) >> 3;
+        unsigned i = 0;
+        if (lane == 0) i = atomicAdd(&counters[ct], 1u) + (unsigned)first_t;
+        i = (unsigned)__builtin_amdgcn_readfirstlane((int)i);
+        if (i < (unsigned)n_t) item = ct + 8 * (int)i;
     }
-    return __builtin_amdgcn_readfirstlane(item);
+    return item;
+}
+// The same in two halves, so that the round trip of the first atomic (own class) overlaps the work between them:
+// fetch_begin issues it and returns the raw counter value in lane 0, fetch_end interprets it and only falls back to
+// the other classes (blocking) when the own class is exhausted.
+__device__ __forceinline__ unsigned fetch_begin(unsigned* counters, int xcd, int total, int grid, int lane) {
+    const int n_c = (total - xcd + 7) >> 3, first = (grid - xcd + 7) >> 3;
+    unsigned raw = 0xffffffffu;
+    if (lane == 0 && n_c > first) raw = atomicAdd(&counters[xcd], 1u);
+    return raw;
+}
+__device__ __forceinline__ int fetch_end(unsigned raw, unsigned* counters, int xcd, int total, int grid, int lane) {
+    raw = (unsigned)__builtin_amdgcn_readfirstlane((int)raw);
+    const int n_c = (total - xcd + 7) >> 3, first = (grid - xcd + 7) >> 3;
+    if (raw != 0xffffffffu && raw + (unsigned)first < (unsigned)n_c) return xcd + 8 * (int)(raw + (unsigned)first);
+    return fetch_item(counters, xcd, total, grid, lane, 1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -847,8 +872,7 @@ __device__ __forceinline__ void stream_valu(const AttnParams& p, const PageEntry
 //                                  first half for j < 4 and of the second half for j >= 4), A = V^T read with
 //                                  ds_read_b64_tr_b16 from a row-major image of the tile in LDS (rows padded by
 //                                  32 B: the 8 rows a 32-lane half touches fall into 8 different bank groups).
-// V goes HBM -> VGPR -> LDS (wave-private area, so no workgroup barrier), K never touches LDS.  The next tile's
-// loads are issued before the current tile is computed.  P is split into a high and a low f16 / bf16 part (two
+// V goes HBM -> VGPR -> LDS (wave-private area, so no workgroup barrier), K never touches LDS.  P is split into a high and a low f16 / bf16 part (two
 // MFMAs, the matrix pipe is nearly idle anyway) so that its rounding stays far below the output tolerance.
 // ------------------------------------------------------------------------------------------------
 template <typename KVT, int LPT>
@@ -1186,7 +1210,9 @@ void attn_kernel(const AttnParams p) {
     };
     // item < 0: fetch the next one; stage: 0 nothing done yet, 1 the keys of this item are already in LDS,
     // 2 the rows' page lists are done as well (bitmaps in pbits_all, lengths in row_lens)
-    auto build = [&](int slot, int item, int stage) {
+    // raw_next: the value of fetch_begin when the caller has issued it already (first item), else kNoFetch
+    constexpr unsigned kNoFetch = 0xfffffffeu;
+    auto build = [&](int slot, int item, int stage, unsigned raw_next) {
         ItemHdr* hdr = hdr_at(slot);
         PageEntry* list = lists + (size_t)slot * p.max_entries;
         float* qst = qsts + (size_t)slot * nq * D;
@@ -1195,6 +1221,11 @@ void attn_kernel(const AttnParams p) {
             if (lane == 0 && sidx == 0) hdr->item = -1;
             return;
         }
+        // claim the item after this one now (the leader; the answer is needed at the end): whether this is the
+        // workgroup's last item must be known before it is streamed
+        const bool dynamic = total > (int)gridDim.x;
+        if (raw_next == kNoFetch && dynamic && sidx == 0)
+            raw_next = fetch_begin(p.counters, xcd, total, (int)gridDim.x, lane);
         const ItemCtx ctx = decode(item);
         const int b = ctx.b, n2 = ctx.n2, head0 = ctx.head0, R = ctx.R;
         const long long row0 = ctx.row0;
@@ -1282,9 +1313,7 @@ void attn_kernel(const AttnParams p) {
             qst[t] = v;
         }
         SPFA_STAMP(6);
-        // claim the item after this one now: whether this is the workgroup's last item must be known before it is
-        // streamed
-        const int nxt = total > (int)gridDim.x ? fetch_item(p.counters, xcd, total, (int)gridDim.x, lane) : -1;
+        const int nxt = dynamic ? fetch_end(raw_next, p.counters, xcd, total, (int)gridDim.x, lane) : -1;
         SPFA_STAMP(1);
         nU = min(nU, p.max_entries);
         int pc = 0, nch = 0;
@@ -1416,6 +1445,9 @@ void attn_kernel(const AttnParams p) {
     {
         const int item0 = (int)blockIdx.x;   // grid <= total
         int stage0 = 1;
+        unsigned raw0 = kNoFetch;
+        if (wave == kStreamWaves && total > (int)gridDim.x)
+            raw0 = fetch_begin(p.counters, xcd, total, (int)gridDim.x, lane);
         if (p.mode == 1) {
             const ItemCtx c0 = decode(item0);
             score_rows<WAVES>(p.q, p.cent, p.q_dtype, c0.row0, c0.n2, c0.R, D, p.C, p.Cp, keys, wave);
@@ -1432,7 +1464,7 @@ void attn_kernel(const AttnParams p) {
                 stage0 = 2;
             }
         }
-        if (selector) build(0, item0, stage0);
+        if (selector) build(0, item0, stage0, raw0);
     }
     __syncthreads();
     if (wave == 0) SPFA_STAMP(14);
@@ -1458,7 +1490,7 @@ void attn_kernel(const AttnParams p) {
         const int nch = __builtin_amdgcn_readfirstlane(h->nch);
         if (have_prev && !selector) finalize(slot ^ 1, prev_row0, prev_R, prev_n2, state_target(prev_shared));
         if (item < 0) break;
-        if (selector) build(slot ^ 1, next, 0);
+        if (selector) build(slot ^ 1, next, 0, kNoFetch);
         else {
             if (wave == 0) SPFA_STAMP(8);
             PageCursor cur;
