@@ -185,3 +185,33 @@ def test_ragged_lengths_bf16_gqa_full_batch():
     assert bool((pos.long()[live] < page_len[:, None, None].expand(-1, a.heads, 256)[live]).all())
     del wl
     torch.cuda.empty_cache()
+
+
+def test_last_item_sharing_with_uneven_items():
+    """Ragged lengths and an unbudgeted cluster map make the items of a launch very unequal, so workgroups that run
+    dry take chunks of other workgroups' last items.  Every launch must reproduce the result of the launch without
+    sharing up to the order of the fp32 partial sums, and the oracle on sampled sequences."""
+    from custom_ops import _abi
+    a = args(seqlen=32768, clusters=256, topk=48)
+    wl = bench.build_workload(a, torch.device(DEV), a.batch, a.seed, custom_ops)
+    g = torch.Generator(device=DEV)
+    g.manual_seed(11)
+    seq = torch.randint(1, a.seqlen + 1, (a.batch,), generator=g, device=DEV, dtype=torch.int32)
+    seq[:4] = torch.tensor([a.seqlen, 1, 4097, 129], dtype=torch.int32, device=DEV)
+    wl["seq"] = seq
+    # cluster ids drawn at random: a head selects about k / C of its pages, between none and ~80
+    wl["block_ids"] = torch.randint(0, a.clusters, wl["block_ids"].shape, generator=g, device=DEV, dtype=torch.int32)
+    _abi.check(_abi.spfaSetTailSharing(0), "spfaSetTailSharing")
+    try:
+        det, dpos, dlen, dmax = run_fused(a, wl)
+    finally:
+        _abi.spfaSetTailSharing(1)
+    assert int(dlen[:, :, 0].max()) > 2 * int(dlen[:, :, 0].float().mean()) or int(dlen[:, :, 0].min()) == 0
+    check_against_oracle(a, wl, det, dpos, dlen, dmax, [0, 2, 33])
+    scale = float(det.abs().max())
+    for _ in range(12):
+        out, pos, plen, pmax = run_fused(a, wl)
+        assert torch.equal(pos, dpos) and torch.equal(plen, dlen) and torch.equal(pmax, dmax)
+        assert float((out - det).abs().max()) <= 2e-6 * scale
+    del wl
+    torch.cuda.empty_cache()
