@@ -283,7 +283,7 @@ def main():
                    "pages_selected_per_launch": pages, "parallelism": f"batch-shard x{world}"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": kernel_ms,
-                     "algorithmic_bytes_per_launch": gbytes},
+                     "algorithmic_bytes_per_launch": gbytes, "scope": "one GPU (rank 0)"},
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:

@@ -1,0 +1,134 @@
+"""Phase 1 of the aclnn ABI is synchronous host code: validation and launch planning can be exercised without a GPU.
+Descriptors carry fake device addresses (never dereferenced, nothing is launched).  The error cases are the ones the
+reference's host checks name (sparse_paged_fusion_attention_tiling_check.cc:28-48,171-222,497-525)."""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_int, c_int64, c_uint64, c_void_p
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "cann-ops-adv-vllm_amd", "lib", "libcust_opapi.so")
+F32, F16, I8, I32, I64, BF16 = 0, 1, 2, 3, 9, 27
+PARAM_NULL, PARAM_INVALID = 161001, 161002
+
+
+@pytest.fixture(scope="module")
+def lib():
+    L = ctypes.CDLL(LIB)
+    L.aclCreateTensor.restype = c_void_p
+    L.aclCreateTensor.argtypes = [POINTER(c_int64), c_uint64, c_int, POINTER(c_int64), c_int64, c_int,
+                                  POINTER(c_int64), c_uint64, c_void_p]
+    L.aclCreateTensorList.restype = c_void_p
+    L.aclCreateTensorList.argtypes = [POINTER(c_void_p), c_uint64]
+    L.aclCreateIntArray.restype = c_void_p
+    L.aclCreateIntArray.argtypes = [POINTER(c_int64), c_uint64]
+    L.aclGetRecentErrMsg.restype = c_char_p
+    L.aclDestroyAclOpExecutor.argtypes = [c_void_p]
+    T = c_void_p
+    attrs = [c_int64, c_double, c_char_p, c_int64, c_int64, c_int64]
+    L.aclnnSparsePagedAttentionGetWorkspaceSize.argtypes = [T] * 16 + attrs + [T, POINTER(c_uint64), POINTER(T)]
+    L.aclnnSparsePagedFusionAttentionGetWorkspaceSize.argtypes = [T] * 18 + attrs + [T] * 4 + [POINTER(c_uint64), POINTER(T)]
+    L.aclnnCentSelectGetWorkspaceSize.argtypes = [T] * 9 + [POINTER(c_uint64), POINTER(T)]
+    return L
+
+
+def tensor(lib, shape, dtype, addr=0x10000):
+    n = len(shape)
+    dims = (c_int64 * n)(*shape)
+    strides = [1] * n
+    for i in range(n - 2, -1, -1):
+        strides[i] = strides[i + 1] * shape[i + 1]
+    return lib.aclCreateTensor(dims, n, dtype, (c_int64 * n)(*strides), 0, 2, dims, n, c_void_p(addr))
+
+
+def tlist(lib, t):
+    return lib.aclCreateTensorList((c_void_p * 1)(t), 1)
+
+
+def attention(lib, *, Hq=8, Hkv=2, D=128, bs=128, B=3, q_dtype=F16, kv_dtype=F16, kv_shape=None, layout=b"BNSD",
+              pos_rows=None, antiq=None, out_dtype=None, pse=None):
+    q = tensor(lib, (B, Hq, D), q_dtype)
+    kv_shape = kv_shape or (40, bs, Hkv, D)
+    k, v = tlist(lib, tensor(lib, kv_shape, kv_dtype)), tlist(lib, tensor(lib, kv_shape, kv_dtype))
+    table = tensor(lib, (B, 24), I32)
+    pos = tensor(lib, (B, pos_rows or Hkv, 12), I32)
+    out = tensor(lib, (B, Hq, D), out_dtype if out_dtype is not None else q_dtype)
+    ws, ex = c_uint64(0), c_void_p()
+    st = lib.aclnnSparsePagedAttentionGetWorkspaceSize(
+        q, k, v, pse, None, None, None, None, None, None, None, antiq, None, table, None, pos,
+        Hq, 0.088, layout, Hkv, bs, 1, out, ctypes.byref(ws), ctypes.byref(ex))
+    if st == 0:
+        lib.aclDestroyAclOpExecutor(ex)
+    return st, ws.value, (lib.aclGetRecentErrMsg() or b"").decode()
+
+
+def test_attention_plans_without_a_device(lib):
+    st, ws, _ = attention(lib)
+    assert st == 0 and ws >= 256            # the work counters; no split / sharing areas without a device to size them
+    st, ws2, _ = attention(lib, pos_rows=8)  # one list per q head
+    assert st == 0
+    st, _, _ = attention(lib, kv_shape=(40, 2, 128, 128))          # [blocks, Hkv, bs, D]
+    assert st == 0
+    st, _, _ = attention(lib, q_dtype=BF16, kv_dtype=BF16, out_dtype=F32)
+    assert st == 0
+
+
+@pytest.mark.parametrize("kw,fragment", [
+    (dict(bs=100), "blockSize"),                     # not a multiple of 16
+    (dict(bs=1024, kv_shape=(40, 1024, 2, 128)), "blockSize"),      # > 512
+    (dict(bs=48, kv_dtype=I8, kv_shape=(40, 48, 2, 128)), "multiple of 32"),
+    (dict(Hq=130, Hkv=2), "group size"),             # G = 65 > 64
+    (dict(Hq=8, Hkv=3), "not divisible"),
+    (dict(kv_dtype=BF16), "KV cache dtype"),         # f16 query with bf16 cache
+    (dict(kv_dtype=I8), "int8 KV cache needs"),      # no antiquantScale
+    (dict(pos_rows=3), "blockposition"),
+    (dict(kv_shape=(40, 128, 2, 64)), "KV cache must be"),
+    (dict(out_dtype=I32), "attentionOut dtype"),
+    (dict(D=80, kv_shape=(40, 128, 2, 80)), "head dim"),
+])
+def test_attention_rejects(lib, kw, fragment):
+    st, _, msg = attention(lib, **kw)
+    assert st == PARAM_INVALID, msg
+    assert fragment in msg, msg
+
+
+def test_unsupported_operands_and_null_pointers(lib):
+    st, _, msg = attention(lib, pse=tensor(lib, (3, 8, 1, 12), F16))
+    assert st == PARAM_INVALID and "pseShift" in msg
+    st, _, msg = attention(lib, antiq=tensor(lib, (2, 2, 128), F16))
+    assert st == PARAM_INVALID and "antiquant" in msg
+    ws, ex = c_uint64(0), c_void_p()
+    q = tensor(lib, (3, 8, 128), F16)
+    st = lib.aclnnCentSelectGetWorkspaceSize(q, None, None, None, None, None, None, None, None, ctypes.byref(ws),
+                                             ctypes.byref(ex))
+    assert st == PARAM_NULL and b"l1_cent" in lib.aclGetRecentErrMsg()
+
+
+def test_fusion_plan_and_mismatches(lib):
+    B, Hq, Hkv, D, C, bs = 4, 8, 2, 128, 512, 128
+    def call(l1_shape=(Hkv, C, D), ids_rows=Hkv, seq_dtype=I32, pos_shape=(B, Hq, 256)):
+        q = tensor(lib, (B, Hq, D), F16)
+        k = tlist(lib, tensor(lib, (64, bs, Hkv, D), F16))
+        v = tlist(lib, tensor(lib, (64, bs, Hkv, D), F16))
+        args = [q, k, v] + [None] * 10 + [tensor(lib, (B, 16), I32), None, tensor(lib, l1_shape, F16),
+                                          tensor(lib, (ids_rows, 64), I32), tensor(lib, (B,), seq_dtype)]
+        outs = [tensor(lib, pos_shape, I32), tensor(lib, (B, Hq, 8), I32), tensor(lib, (B, 8), I64),
+                tensor(lib, (B, Hq, D), F16)]
+        ws, ex = c_uint64(0), c_void_p()
+        st = lib.aclnnSparsePagedFusionAttentionGetWorkspaceSize(*args, Hq, 0.088, b"BNSD", Hkv, bs, 1, *outs,
+                                                                 ctypes.byref(ws), ctypes.byref(ex))
+        if st == 0:
+            lib.aclDestroyAclOpExecutor(ex)
+        return st, (lib.aclGetRecentErrMsg() or b"").decode()
+    assert call()[0] == 0
+    st, msg = call(l1_shape=(Hkv, 32, D))            # default top-k 64 > 32 clusters
+    assert st == PARAM_INVALID and "top-k" in msg
+    st, msg = call(ids_rows=3)
+    assert st == PARAM_INVALID and "block_ids" in msg
+    st, msg = call(seq_dtype=I64)                    # total_seq_len is int32 in the reference (…Us2.h:1664)
+    assert st == PARAM_INVALID and "seq_len" in msg
+    st, msg = call(pos_shape=(B, Hkv, 256))          # the fused op writes one row per q head
+    assert st == PARAM_INVALID and "block_position" in msg
+    st, msg = call(l1_shape=(4, C, D))
+    assert st == PARAM_INVALID
