@@ -41,6 +41,7 @@ struct aclOpExecutor {
     // workspace layout of the two attention ops: [work counters | split arrival counters] (zeroed per launch),
     // split states, per-batch actualSeqLengths
     uint64_t ws_zero_bytes = 0, ws_parts_off = 0, ws_lengths_off = 0, ws_boards_off = 0, ws_tail_off = 0;
+    uint64_t ws_pgdone_off = 0, ws_pgkeys_off = 0;
     uint64_t ws_bytes = 0;
 };
 
@@ -52,6 +53,7 @@ thread_local int g_sink_recent = 0;
 thread_local int g_page_cap = 0;
 thread_local int g_max_split = 16;
 thread_local int g_tail_sharing = 1;
+thread_local int g_shared_scoring = 1;
 thread_local int64_t g_page_size = 128;   // PAGESIZE of cent_select.cpp:17 / select_position.cpp:112
 thread_local const long long* g_act_seq_dev = nullptr;   // one-shot, consumed by the next attention plan
 thread_local int64_t g_act_seq_dev_n = 0;
@@ -255,6 +257,7 @@ aclnnStatus spfaSetMaxSplit(int64_t max_split) {
     return ACLNN_SUCCESS;
 }
 aclnnStatus spfaSetTailSharing(int enable) { g_tail_sharing = enable ? 1 : 0; return ACLNN_SUCCESS; }
+aclnnStatus spfaSetSharedScoring(int enable) { g_shared_scoring = enable ? 1 : 0; return ACLNN_SUCCESS; }
 aclnnStatus spfaSetPageSize(int64_t page_size) {
     if (page_size < 1 || page_size > 512) return fail(ACLNN_ERR_PARAM_INVALID, "page size %lld out of [1, 512]", (long long)page_size);
     g_page_size = page_size;
@@ -620,12 +623,18 @@ static void plan_workspace(aclOpExecutor* e) {
     p.tail_chunks = p.rows_per_pass == 1 ? 32 : 16;   // one state per chunk + the owner's: keep the wide ones fewer
     p.tail_stride = (long long)up256(32 + (uint64_t)p.max_entries * 8 + (mfma ? 0 : (uint64_t)p.rows_per_pass * p.D * 4) + 16 +
                                      (uint64_t)(p.tail_chunks + 1) * state_bytes);
+    // Shared first scoring (fused op with a page-list split): the workgroups of one item score its rows together.
+    uint64_t n_groups = 0;
+    if (p.mode == 1 && p.n_split > 1 && g_shared_scoring) n_groups = (uint64_t)items;
+    p.pg_on = n_groups > 0 ? 1 : 0;
     e->ws_boards_off = kCounterBytes + (p.n_split > 1 ? up256((uint64_t)items * 4) : 0);
-    e->ws_zero_bytes = e->ws_boards_off + up256(n_boards * 16);
+    e->ws_pgdone_off = e->ws_boards_off + up256(n_boards * 16);
+    e->ws_zero_bytes = e->ws_pgdone_off + up256(n_groups * 4);
     e->ws_parts_off = e->ws_zero_bytes;
     const uint64_t parts = p.n_split > 1 ? up256((uint64_t)items * p.n_split * state_bytes) : 0;
     e->ws_tail_off = e->ws_parts_off + parts;
-    e->ws_lengths_off = e->ws_tail_off + n_boards * (uint64_t)p.tail_stride;
+    e->ws_pgkeys_off = e->ws_tail_off + n_boards * (uint64_t)p.tail_stride;
+    e->ws_lengths_off = e->ws_pgkeys_off + n_groups * 16ull * p.Cp * 4;
     e->ws_bytes = e->ws_lengths_off + (e->act_seq.empty() ? 0 : up256((uint64_t)p.B * 8));
 }
 
@@ -636,6 +645,8 @@ static hipError_t bind_workspace(const aclOpExecutor* e, spfa::AttnParams& p, vo
     p.split_partials = (float*)((char*)workspace + e->ws_parts_off);
     p.tail_boards = (char*)workspace + e->ws_boards_off;
     p.tail_data = (char*)workspace + e->ws_tail_off;
+    p.pg_done = (unsigned*)((char*)workspace + e->ws_pgdone_off);
+    p.pg_keys = (uint32_t*)((char*)workspace + e->ws_pgkeys_off);
     return hipMemsetAsync(workspace, 0, e->ws_zero_bytes, stream);
 }
 

@@ -52,6 +52,18 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// Data that one workgroup hands to another inside a launch is written and read with agent-scope accesses, which go
+// past the non-coherent cache levels, and the writer waits for its stores before it signals with an atomic.  No
+// release/acquire fence is used: on this part a fence writes back / invalidates a whole L2, and hundreds of them per
+// XCD while the other workgroups still stream K/V cost more than the sharing saves.
+template <typename T>
+__device__ __forceinline__ void st_agent(T* ptr, T v) { __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename T>
+__device__ __forceinline__ T ld_agent(const T* ptr) {
+    return __hip_atomic_load(const_cast<T*>(ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void wait_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // fp32 -> uint32 whose unsigned order equals the float order (-0 == +0, +NaN largest).
 __device__ __forceinline__ uint32_t score_key(float x) {
     x = x + 0.0f;
@@ -92,9 +104,12 @@ __device__ __forceinline__ float load_qk_elem(const void* p, int dtype, long lon
 // the store), so one round trip to L2 brings 16 KiB per wave instead of 1 KiB.
 // Row r of the tile is q row q_row0 + (r / rpb) * b_stride + r % rpb: rpb consecutive heads of one sequence, then the
 // same heads of the next sequence b_stride rows further (rpb = R: all rows consecutive).
+// The WAVES waves of a workgroup share the tiles; with nparts > 1 the workgroup is one of nparts that share them (it
+// takes every nparts-th group of tiles) and the keys go to global memory with agent-scope stores.
 template <int WAVES, bool BF16, int KS>
 __device__ __forceinline__ void score_rows_impl(const void* q, const void* cent, long long q_row0, int n2, int R,
-                                                int C, int Cp, uint32_t* keys, int wave, int rpb, int b_stride) {
+                                                int C, int Cp, uint32_t* keys, int wave, int rpb, int b_stride,
+                                                int part, int nparts) {
     constexpr int D = KS * 32;
     constexpr int TG = 16 / KS;   // tiles per group: TG * KS = 16 loads in flight
     const int lane = lane_id();
@@ -110,7 +125,7 @@ __device__ __forceinline__ void score_rows_impl(const void* q, const void* cent,
     }
     const char* cbase = (const char*)cent + (long long)n2 * C * D * 2 + kq * 16;
     const int ntiles = Cp >> 4;   // Cp % 128 == 0: a multiple of every TG
-    for (int t0 = wave * TG; t0 < ntiles; t0 += WAVES * TG) {
+    for (int t0 = (part * WAVES + wave) * TG; t0 < ntiles; t0 += nparts * WAVES * TG) {
         uint4 bv[TG][KS];
 #pragma unroll
         for (int j = 0; j < TG; ++j) {
@@ -135,7 +150,11 @@ __device__ __forceinline__ void score_rows_impl(const void* q, const void* cent,
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int qr = kq * 4 + r;
-                if (qr < R) keys[qr * Cp + c] = (c < C) ? score_key(acc[r]) : 0u;
+                if (qr < R) {
+                    const uint32_t key = (c < C) ? score_key(acc[r]) : 0u;
+                    if (nparts > 1) st_agent(keys + qr * Cp + c, key);
+                    else keys[qr * Cp + c] = key;
+                }
             }
         }
     }
@@ -145,11 +164,13 @@ __device__ __forceinline__ void score_rows_impl(const void* q, const void* cent,
 template <int WAVES>
 __device__ __forceinline__ void score_rows(const void* q, const void* cent, int dtype, long long q_row0,
                                            int n2, int R, int D, int C, int Cp, uint32_t* keys, int widx,
-                                           int rpb = 16, int b_stride = 0) {
+                                           int rpb = 16, int b_stride = 0, int part = 0, int nparts = 1) {
 #define SPFA_SCORE(KS)                                                                              \
     case KS:                                                                                        \
-        if (dtype == kBF16) score_rows_impl<WAVES, true, KS>(q, cent, q_row0, n2, R, C, Cp, keys, widx, rpb, b_stride);  \
-        else score_rows_impl<WAVES, false, KS>(q, cent, q_row0, n2, R, C, Cp, keys, widx, rpb, b_stride);                \
+        if (dtype == kBF16)                                                                           \
+            score_rows_impl<WAVES, true, KS>(q, cent, q_row0, n2, R, C, Cp, keys, widx, rpb, b_stride, part, nparts);  \
+        else                                                                                          \
+            score_rows_impl<WAVES, false, KS>(q, cent, q_row0, n2, R, C, Cp, keys, widx, rpb, b_stride, part, nparts); \
         break;
     switch (D >> 5) {
         SPFA_SCORE(1)
@@ -664,18 +685,6 @@ struct TailHdr {             // 32 bytes at the start of a board's data area, wr
 };
 constexpr int kHdrSlot = 48;                        // bytes per ItemHdr slot in LDS
 constexpr int kTailChunksMax = 32;                  // chunks per shared item (AttnParams::tail_chunks <= this)
-
-// Data that one workgroup hands to another inside a launch is written and read with agent-scope accesses, which go
-// past the non-coherent cache levels, and the writer waits for its stores before it signals with an atomic.  No
-// release/acquire fence is used: on this part a fence writes back / invalidates a whole L2, and hundreds of them per
-// XCD while the other workgroups still stream K/V cost more than the sharing saves.
-template <typename T>
-__device__ __forceinline__ void st_agent(T* ptr, T v) { __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-template <typename T>
-__device__ __forceinline__ T ld_agent(const T* ptr) {
-    return __hip_atomic_load(const_cast<T*>(ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void wait_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // Page cursor of one streamer wave: static striding (wave, wave + 4, ...) or chunk claims from a board.
 struct PageCursor {
@@ -1450,8 +1459,38 @@ void attn_kernel(const AttnParams p) {
             raw0 = fetch_begin(p.counters, xcd, total, (int)gridDim.x, lane);
         if (p.mode == 1) {
             const ItemCtx c0 = decode(item0);
-            score_rows<WAVES>(p.q, p.cent, p.q_dtype, c0.row0, c0.n2, c0.R, D, p.C, p.Cp, keys, wave);
-            __syncthreads();
+            // Page-list split: the NS workgroups of an item all need the very same rows.  Each scores every NS-th
+            // tile group into global memory and takes the full rows back once the others have delivered (a bounded
+            // wait; a workgroup that gives up scores its rows alone).  Sharing a pass between DIFFERENT items of
+            // one kv head in large launches was measured too: the hand-off costs more than the 31 us pass.
+            bool have_keys = false;
+            if (p.pg_on && NS > 1) {
+                const int gid = item0 / NS;
+                uint32_t* gkeys = p.pg_keys + (size_t)gid * 16 * p.Cp;
+                score_rows<WAVES>(p.q, p.cent, p.q_dtype, c0.row0, c0.n2, c0.R, D, p.C, p.Cp, gkeys, wave, c0.R, 0,
+                                  c0.split, NS);
+                wait_stores();
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    atomicAdd(p.pg_done + gid, 1u);
+                    int spins = 0;
+                    while (ld_agent(p.pg_done + gid) < (unsigned)NS && spins < (1 << 16)) {
+                        __builtin_amdgcn_s_sleep(8);
+                        ++spins;
+                    }
+                    team[2] = ld_agent(p.pg_done + gid) >= (unsigned)NS ? 1 : 0;
+                }
+                __syncthreads();
+                if (team[2]) {
+                    for (int t = threadIdx.x; t < c0.R * p.Cp; t += WAVES * 64) keys[t] = ld_agent(gkeys + t);
+                    have_keys = true;
+                }
+                __syncthreads();
+            }
+            if (!have_keys) {
+                score_rows<WAVES>(p.q, p.cent, p.q_dtype, c0.row0, c0.n2, c0.R, D, p.C, p.Cp, keys, wave);
+                __syncthreads();
+            }
             if (wave == 0) SPFA_STAMP(12);
             if (c0.R > 1) {   // one wave per row instead of the selector walking all of them
                 const int page_len = page_len_of(c0.b);

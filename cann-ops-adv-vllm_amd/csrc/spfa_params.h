@@ -91,6 +91,10 @@ struct AttnParams {
     void* tail_boards;             // [2 * #CU] 16-byte boards, zeroed before every launch
     char* tail_data;               // [2 * #CU] data areas of tail_stride bytes
     long long tail_stride;
+    // shared first scoring (fused op): groups of workgroups score their first items' rows in one centroid pass
+    int pg_on;
+    unsigned* pg_done;             // [groups] arrival counters (workspace), zeroed before every launch
+    uint32_t* pg_keys;             // [groups][16][Cp] score keys
     unsigned* split_done;          // [items] arrival counters (workspace), zeroed before every launch
     float* split_partials;         // [items * n_split][rows_per_pass][D + 2] un-normalised states (workspace)
     unsigned long long* debug;     // diagnostic builds only: [grid][16 items][16 stamps], else null

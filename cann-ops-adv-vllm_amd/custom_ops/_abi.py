@@ -56,6 +56,7 @@ spfaSetSinkRecent = _sig("spfaSetSinkRecent", c_int, [c_int])
 spfaSetPageCap = _sig("spfaSetPageCap", c_int, [c_int])
 spfaSetMaxSplit = _sig("spfaSetMaxSplit", c_int, [c_int64])
 spfaSetTailSharing = _sig("spfaSetTailSharing", c_int, [c_int])
+spfaSetSharedScoring = _sig("spfaSetSharedScoring", c_int, [c_int])
 spfaSetPageSize = _sig("spfaSetPageSize", c_int, [c_int64])
 spfaSetActualSeqLengthsDevice = _sig("spfaSetActualSeqLengthsDevice", c_int, [c_void_p, c_int64])
 spfaVersion = _sig("spfaVersion", c_char_p, [])

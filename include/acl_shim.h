@@ -102,6 +102,10 @@ SPFA_API aclnnStatus spfaSetMaxSplit(int64_t maxSplit);
  * workgroups which ran out of work may take over (states merged in the same launch; workspace grows by one data
  * area per resident workgroup).  0 turns it off.  Default on. */
 SPFA_API aclnnStatus spfaSetTailSharing(int enable);
+/* Fused op with a page-list split: the workgroups of one item score its rows in one shared pass over the centroids
+ * and exchange the score keys through the workspace (a bounded wait; a workgroup that gives up scores alone).
+ * 0 turns it off.  Default on. */
+SPFA_API aclnnStatus spfaSetSharedScoring(int enable);
 /* page size of the two ops without a blockSize attribute (CentSelect, SelectPosition); the reference
  * compiles in 128 (cent_select.cpp:17, select_position.cpp:112).  Default 128. */
 SPFA_API aclnnStatus spfaSetPageSize(int64_t pageSize);

@@ -319,6 +319,13 @@ def test_page_list_split_equals_single_workgroup(H, Hq, Hkv, kvdt):
             res[("sep", max_split)] = sep
         finally:
             _abi.spfaSetMaxSplit(16)
+    # the split workgroups of an item score its rows in one shared pass; without that every one scores alone
+    _abi.check(_abi.spfaSetSharedScoring(0), "spfaSetSharedScoring")
+    try:
+        alone = H.call_fusion(qd, kd, vd, td, l1d, idsd, seqd, Hq, Hkv, D ** -0.5, bs, topk, out_dtype=torch.float32, **kw)
+    finally:
+        _abi.spfaSetSharedScoring(1)
+    assert all(torch.equal(x, y) for x, y in zip(alone, res[16]))
     out1, pos1, len1, max1 = res[1]
     scale = float(out1.abs().max())
     for ms in (16, 3):
