@@ -1675,7 +1675,7 @@ void attn_kernel(const AttnParams p) {
 }
 
 template <typename KVT, int NQ, int LPT, bool MFMA>
-hipError_t launch_attn_one(const AttnParams& p, hipStream_t s) {
+hipError_t launch_attn_one(const AttnParams& p, hipStream_t s, long long* cap_out) {
     auto kern = attn_kernel<KVT, NQ, LPT, MFMA>;
     if (p.lds_bytes > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1694,8 +1694,9 @@ hipError_t launch_attn_one(const AttnParams& p, hipStream_t s) {
     const int g_eff = per_head ? 1 : p.G;
     const int nq = MFMA ? p.rows_per_pass : NQ;
     const long long total = (long long)p.B * (per_head ? p.Hq : p.Hkv) * ((g_eff + nq - 1) / nq) * p.n_split;
-    if (total == 0) return hipSuccess;
+    if (total == 0 && !cap_out) return hipSuccess;
     const long long cap = (long long)n_cu * blocks_per_cu;
+    if (cap_out) { *cap_out = cap; return hipSuccess; }   // planning: how many workgroups can be resident
     if (p.n_split > 1 && total > cap) return hipErrorInvalidConfiguration;   // a split needs one workgroup per unit
     const dim3 grid((unsigned)(total < cap ? total : cap));
     static bool said = false;
@@ -1710,30 +1711,30 @@ hipError_t launch_attn_one(const AttnParams& p, hipStream_t s) {
 
 // One q head per pass (MHA, or a group whose heads bring their own lists), or int8 KV: VALU streamer.
 template <typename KVT, int NQ>
-hipError_t launch_attn_valu(const AttnParams& p, int lpt, hipStream_t s) {
+hipError_t launch_attn_valu(const AttnParams& p, int lpt, hipStream_t s, long long* cap_out) {
     switch (lpt) {
 #ifndef SPFA_EXPLORE
-        case 4: return launch_attn_one<KVT, NQ, 4, false>(p, s);
-        case 8: return launch_attn_one<KVT, NQ, 8, false>(p, s);
-        case 32: return launch_attn_one<KVT, NQ, 32, false>(p, s);
+        case 4: return launch_attn_one<KVT, NQ, 4, false>(p, s, cap_out);
+        case 8: return launch_attn_one<KVT, NQ, 8, false>(p, s, cap_out);
+        case 32: return launch_attn_one<KVT, NQ, 32, false>(p, s, cap_out);
 #endif
-        case 16: return launch_attn_one<KVT, NQ, 16, false>(p, s);
+        case 16: return launch_attn_one<KVT, NQ, 16, false>(p, s, cap_out);
     }
     return hipErrorInvalidValue;
 }
 
 // Several q heads share the K/V rows (f16 / bf16): MFMA streamer.
 template <typename KVT>
-hipError_t launch_attn_mfma(const AttnParams& p, int lpt, hipStream_t s) {
+hipError_t launch_attn_mfma(const AttnParams& p, int lpt, hipStream_t s, long long* cap_out) {
     switch (lpt) {
 #ifndef SPFA_EXPLORE
-        case 4: return launch_attn_one<KVT, 16, 4, true>(p, s);
-        case 8: return launch_attn_one<KVT, 16, 8, true>(p, s);
+        case 4: return launch_attn_one<KVT, 16, 4, true>(p, s, cap_out);
+        case 8: return launch_attn_one<KVT, 16, 8, true>(p, s, cap_out);
         case 32:
-            if constexpr (sizeof(KVT) == 2) return launch_attn_one<KVT, 16, 32, true>(p, s);
+            if constexpr (sizeof(KVT) == 2) return launch_attn_one<KVT, 16, 32, true>(p, s, cap_out);
             break;
 #endif
-        case 16: return launch_attn_one<KVT, 16, 16, true>(p, s);
+        case 16: return launch_attn_one<KVT, 16, 16, true>(p, s, cap_out);
     }
     return hipErrorInvalidValue;
 }
@@ -1758,37 +1759,37 @@ int attention_rows_per_pass(int G, int kv_dtype, int D) {
     return G < 16 ? G : 16;                     // MFMA streamer: up to 16 columns
 }
 
-hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
+hipError_t launch_attention(const AttnParams& p, hipStream_t s, long long* cap_out) {
     const int nq = p.rows_per_pass;
     const int esize = (p.kv_dtype == kI8) ? 1 : 2;
     const int lpt = p.D * esize / 16;
     if (attention_uses_mfma(nq, p.kv_dtype, p.D)) {
         if (nq > 16) return hipErrorInvalidValue;
 #ifdef SPFA_EXPLORE
-        if (p.kv_dtype == kF16) return launch_attn_mfma<_Float16>(p, lpt, s);
+        if (p.kv_dtype == kF16) return launch_attn_mfma<_Float16>(p, lpt, s, cap_out);
 #ifdef SPFA_EXPLORE_I8
-        if (p.kv_dtype == kI8 && lpt == 8) return launch_attn_one<int8_t, 16, 8, true>(p, s);
+        if (p.kv_dtype == kI8 && lpt == 8) return launch_attn_one<int8_t, 16, 8, true>(p, s, cap_out);
 #endif
         return hipErrorInvalidValue;
 #else
         switch (p.kv_dtype) {
-            case kF16: return launch_attn_mfma<_Float16>(p, lpt, s);
-            case kBF16: return launch_attn_mfma<__bf16>(p, lpt, s);
-            case kI8: return launch_attn_mfma<int8_t>(p, lpt, s);
+            case kF16: return launch_attn_mfma<_Float16>(p, lpt, s, cap_out);
+            case kBF16: return launch_attn_mfma<__bf16>(p, lpt, s, cap_out);
+            case kI8: return launch_attn_mfma<int8_t>(p, lpt, s, cap_out);
         }
         return hipErrorInvalidValue;
 #endif
     }
     switch (p.kv_dtype) {
-        case kF16: if (nq == 1) return launch_attn_valu<_Float16, 1>(p, lpt, s); break;
+        case kF16: if (nq == 1) return launch_attn_valu<_Float16, 1>(p, lpt, s, cap_out); break;
 #ifdef SPFA_EXPLORE_I8
-        case kI8: if (nq == 1 && lpt == 8) return launch_attn_one<int8_t, 1, 8, false>(p, s); break;
+        case kI8: if (nq == 1 && lpt == 8) return launch_attn_one<int8_t, 1, 8, false>(p, s, cap_out); break;
 #endif
 #ifndef SPFA_EXPLORE
-        case kBF16: if (nq == 1) return launch_attn_valu<__bf16, 1>(p, lpt, s); break;
+        case kBF16: if (nq == 1) return launch_attn_valu<__bf16, 1>(p, lpt, s, cap_out); break;
         case kI8:
-            if (nq == 1) return launch_attn_valu<int8_t, 1>(p, lpt, s);
-            if (nq == 4 && lpt == 32) return launch_attn_one<int8_t, 4, 32, false>(p, s);
+            if (nq == 1) return launch_attn_valu<int8_t, 1>(p, lpt, s, cap_out);
+            if (nq == 4 && lpt == 32) return launch_attn_one<int8_t, 4, 32, false>(p, s, cap_out);
             break;
 #endif
     }
