@@ -507,21 +507,25 @@ static aclnnStatus plan_attention(spfa::AttnParams& p, const aclTensor* query, c
 
     if (quant) {
         REQUIRE(!absent(antiquantScale), "int8 KV cache needs antiquantScale");
-        REQUIRE(antiquantScale->dtype == query->dtype && numel(antiquantScale) == 2ll * Hkv * D &&
-                    is_contiguous(antiquantScale),
-                "antiquantScale must be [2, Hkv, D] in the query dtype (…_tiling_check.cc:497-525)");
+        // [2]: one key and one value parameter for the whole tensor (…_tiling.cc:785-793; the value parameter is
+        // element 1, …Us2.h:2036-2038), else per channel
+        const bool per_tensor = antiquantScale->dims.size() == 1 && antiquantScale->dims[0] == 2;
+        const long long want = per_tensor ? 2 : 2ll * Hkv * D;
+        REQUIRE(antiquantScale->dtype == query->dtype && numel(antiquantScale) == want && is_contiguous(antiquantScale),
+                "antiquantScale must be [2, Hkv, D] or [2] in the query dtype (…_tiling_check.cc:497-525)");
         if (!absent(antiquantOffset))
-            REQUIRE(antiquantOffset->dtype == query->dtype && numel(antiquantOffset) == 2ll * Hkv * D &&
-                        is_contiguous(antiquantOffset),
-                    "antiquantOffset must be [2, Hkv, D] in the query dtype");
+            REQUIRE(antiquantOffset->dtype == query->dtype && numel(antiquantOffset) == want &&
+                        antiquantOffset->dims.size() == antiquantScale->dims.size() && is_contiguous(antiquantOffset),
+                    "antiquantOffset must have antiquantScale's shape and the query dtype");
+        p.antiq_per_tensor = per_tensor ? 1 : 0;
     } else {
         REQUIRE(absent(antiquantScale) && absent(antiquantOffset),
                 "antiquant parameters given but the KV cache is not int8 (…_tiling.cc:862-866)");
     }
     CHECK(check_tensor(blocktable, "blocktable", 2, ACL_INT32));
     REQUIRE_PTR(attentionOut, "attentionOut");
-    REQUIRE(attentionOut->dtype == query->dtype || attentionOut->dtype == ACL_FLOAT,
-            "attentionOut dtype must equal the query dtype (or float32)");
+    REQUIRE(attentionOut->dtype == query->dtype || attentionOut->dtype == ACL_FLOAT || attentionOut->dtype == ACL_INT8,
+            "attentionOut dtype must equal the query dtype (or float32, or int8 with quantScale2)");
     REQUIRE(numel(attentionOut) == numel(query) && is_contiguous(attentionOut), "attentionOut must have query's shape");
     if (batch_limit >= 0) {
         REQUIRE(B >= batch_limit, "query batch %d < total_seq_len batch %d", B, batch_limit);
@@ -549,6 +553,67 @@ static aclnnStatus plan_attention(spfa::AttnParams& p, const aclTensor* query, c
     p.antiq_scale = quant ? data_ptr(antiquantScale) : nullptr;
     p.antiq_offset = (quant && !absent(antiquantOffset)) ? data_ptr(antiquantOffset) : nullptr;
     p.debug = (unsigned long long*)g_debug_buf;
+    return ACLNN_SUCCESS;
+}
+
+// Optional operands of the attention core that ride on the same kernels: pseShift / attenMask over the columns of the
+// gathered sequence (…_tiling_check.cc:737-844) and the int8 output quantisation (…_tiling.cc:569-650,
+// …_tiling_check.cc:412-464).  Called once the batch and the table width are known.
+static aclnnStatus plan_extras(spfa::AttnParams& p, const aclTensor* query, const aclTensor* pseShift,
+                               const aclTensor* attenMask, const aclTensor* quantScale2, const aclTensor* quantOffset2,
+                               const aclTensor* attentionOut) {
+    const long long s_max = (long long)p.max_page * p.block_size;   // sMax of the paged cache
+    if (!absent(pseShift)) {
+        REQUIRE(pseShift->dtype == query->dtype, "pseShift dtype must equal the query dtype (…_tiling_check.cc:757)");
+        REQUIRE(pseShift->dims.size() == 4 && is_contiguous(pseShift) && pseShift->data,
+                "pseShift must be a contiguous [B | 1, numHeads, 1, S] tensor");
+        const auto& d = pseShift->dims;
+        REQUIRE((d[0] == 1 || d[0] == p.B) && d[1] == p.Hq && d[2] == 1,
+                "pseShift is (%lld, %lld, %lld, %lld), which does not match (B, N, 1, S) or (1, N, 1, S)", (long long)d[0],
+                (long long)d[1], (long long)d[2], (long long)d[3]);
+        REQUIRE(d[3] >= s_max, "pseShift S %lld is less than sMax %lld (blocktable columns * blockSize)", (long long)d[3],
+                s_max);
+        REQUIRE(p.D % 16 == 0, "with pseShift the head dim must be 16 aligned");
+        p.pse = data_ptr(pseShift);
+        p.pse_b = (int)d[0];
+        p.pse_s = d[3];
+    }
+    if (!absent(attenMask)) {
+        REQUIRE(attenMask->dtype == ACL_BOOL || attenMask->dtype == ACL_INT8 || attenMask->dtype == ACL_UINT8,
+                "attenMask must be bool, int8 or uint8 (…_tiling_check.cc:826-831)");
+        REQUIRE(attenMask->dims.size() >= 2 && is_contiguous(attenMask) && attenMask->data,
+                "attenMask must be a contiguous [B, ..., S] tensor");
+        const long long s = attenMask->dims.back();
+        REQUIRE(attenMask->dims[0] == p.B && numel(attenMask) == (long long)p.B * s,
+                "attenMask must hold one row of S flags per batch (batch %d)", p.B);
+        REQUIRE(s >= s_max, "attenMask S %lld is less than sMax %lld (blocktable columns * blockSize)", s, s_max);
+        p.amask = (const unsigned char*)data_ptr(attenMask);
+        p.amask_s = s;
+    }
+    if (attentionOut->dtype == ACL_INT8) {
+        REQUIRE(!absent(quantScale2), "output data type is int8, but quantScale2 is absent (…_tiling.cc:572)");
+        REQUIRE(quantScale2->dtype == ACL_FLOAT || quantScale2->dtype == ACL_BF16,
+                "quantScale2 must be float32 or bfloat16 (…_tiling.cc:577)");
+        REQUIRE(quantScale2->dtype != ACL_BF16 || query->dtype == ACL_BF16,
+                "bfloat16 quantScale2 needs a bfloat16 query (…_tiling.cc:587)");
+        const long long per_chn = (long long)p.Hq * p.D;
+        const long long n = numel(quantScale2);
+        REQUIRE((n == 1 || n == per_chn) && is_contiguous(quantScale2) && quantScale2->data,
+                "quantScale2 must hold 1 or numHeads * D = %lld values (…_tiling_check.cc:412-464)", per_chn);
+        p.quant_scale2 = data_ptr(quantScale2);
+        p.quant2_dtype = to_dtype(quantScale2->dtype);
+        p.quant2_per_channel = n > 1 ? 1 : 0;
+        if (!absent(quantOffset2)) {
+            REQUIRE(quantOffset2->dtype == quantScale2->dtype,
+                    "quantScale2 and quantOffset2 must have the same dtype (…_tiling.cc:582-586)");
+            REQUIRE(numel(quantOffset2) == n && is_contiguous(quantOffset2) && quantOffset2->data,
+                    "quantOffset2 must have quantScale2's shape");
+            p.quant_offset2 = data_ptr(quantOffset2);
+        }
+    } else {
+        REQUIRE(absent(quantScale2), "output data type is not int8, but quantScale2 exists (…_tiling.cc:598)");
+        REQUIRE(absent(quantOffset2), "output data type is not int8, but quantOffset2 exists (…_tiling.cc:601)");
+    }
     return ACLNN_SUCCESS;
 }
 
@@ -580,7 +645,8 @@ static size_t carve_lds(spfa::AttnParams& p, size_t nq) {
 
 static aclnnStatus plan_lds(spfa::AttnParams& p) {
     const bool per_head = (p.mode == 0 && p.pos_rows == p.Hq && p.G > 1);
-    int nq = per_head ? 1 : spfa::attention_rows_per_pass(p.G, p.kv_dtype, p.D);
+    // pseShift / attenMask index the columns of ONE head's list: every q head runs as its own pass
+    int nq = (per_head || p.pse || p.amask) ? 1 : spfa::attention_rows_per_pass(p.G, p.kv_dtype, p.D);
     size_t need = carve_lds(p, (size_t)nq);
     // a large group with many clusters: fewer q heads per pass (more passes over the pages) until the keys fit
     while (need > kMaxLds && nq > 2 && spfa::attention_uses_mfma(nq, p.kv_dtype, p.D)) {
@@ -669,13 +735,9 @@ aclnnStatus aclnnSparsePagedAttentionGetWorkspaceSize(
     const aclTensor* attentionOut, uint64_t* workspaceSize, aclOpExecutor** executor) {
     REQUIRE_PTR(workspaceSize, "workspaceSize");
     REQUIRE_PTR(executor, "executor");
-    REJECT_PRESENT(pseShift, "pseShift");
-    REJECT_PRESENT(attenMask, "attenMask");
-    REJECT_PRESENT(dequantScale1, "dequantScale1");
+    REJECT_PRESENT(dequantScale1, "dequantScale1");   // int8 queries are not part of this path
     REJECT_PRESENT(quantScale1, "quantScale1");
     REJECT_PRESENT(dequantScale2, "dequantScale2");
-    REJECT_PRESENT(quantScale2, "quantScale2");
-    REJECT_PRESENT(quantOffset2, "quantOffset2");
     REJECT_PRESENT(kvPaddingSize, "kvPaddingSize");
     aclOpExecutor* e = new aclOpExecutor();
     e->op = kOpAttention;
@@ -713,6 +775,8 @@ aclnnStatus aclnnSparsePagedAttentionGetWorkspaceSize(
             e->act_seq.assign(v.begin(), v.begin() + p.B);
         }
     }
+    st = plan_extras(p, query, pseShift, attenMask, quantScale2, quantOffset2, attentionOut);
+    if (st != ACLNN_SUCCESS) return bail(st);
     st = plan_lds(p);
     if (st != ACLNN_SUCCESS) return bail(st);
     plan_workspace(e);
@@ -768,13 +832,9 @@ aclnnStatus aclnnSparsePagedFusionAttentionGetWorkspaceSize(
     aclOpExecutor** executor) {
     REQUIRE_PTR(workspaceSize, "workspaceSize");
     REQUIRE_PTR(executor, "executor");
-    REJECT_PRESENT(pseShift, "pseShift");
-    REJECT_PRESENT(attenMask, "attenMask");
-    REJECT_PRESENT(dequantScale1, "dequantScale1");
+    REJECT_PRESENT(dequantScale1, "dequantScale1");   // int8 queries are not part of this path
     REJECT_PRESENT(quantScale1, "quantScale1");
     REJECT_PRESENT(dequantScale2, "dequantScale2");
-    REJECT_PRESENT(quantScale2, "quantScale2");
-    REJECT_PRESENT(quantOffset2, "quantOffset2");
     REJECT_PRESENT(kvPaddingSize, "kvPaddingSize");
     int Hq = 0, Hkv = 0, D = 0, C = 0;
     CHECK(check_qcent(query, l1_cent, &Hq, &Hkv, &D, &C));
@@ -823,6 +883,8 @@ aclnnStatus aclnnSparsePagedFusionAttentionGetWorkspaceSize(
         p.max_page_position_length = (unsigned long long*)data_ptr(max_page_position_length);
     }
     p.max_entries = max_page;   // the union of a group's lists never exceeds the logical page count
+    st = plan_extras(p, query, pseShift, attenMask, quantScale2, quantOffset2, attentionOut);
+    if (st != ACLNN_SUCCESS) return bail(st);
     st = plan_lds(p);
     if (st != ACLNN_SUCCESS) return bail(st);
     plan_workspace(e);

@@ -735,7 +735,7 @@ struct PageCursor {
 // ------------------------------------------------------------------------------------------------
 template <typename KVT, int NQ, int LPT>
 __device__ __forceinline__ void stream_valu(const AttnParams& p, const PageEntry* list, const float* qst, float* comb,
-                                            PageCursor& cur, int n2, int lane, int wave) {
+                                            PageCursor& cur, int n2, long long row0, int n_base, int lane, int wave) {
     constexpr int EPL = KvTraits<KVT>::EPL;     // elements per 16-byte lane load
     constexpr int TPL = 64 / LPT;               // tokens per wave load
     constexpr int LG = (NQ * EPL <= 16) ? SPFA_LG1 : ((NQ * EPL <= 32) ? SPFA_LGN : 2);   // wave loads of K (and V) per step
@@ -772,6 +772,15 @@ __device__ __forceinline__ void stream_valu(const AttnParams& p, const PageEntry
     // bit pattern in a dead V row would otherwise poison 0 * v).
     const int lane_off = grp * (int)p.tok_stride + sub * 16;
     const int row_bytes = D * (int)sizeof(KVT);
+    // Score bias / mask over the columns of this head's gathered sequence (one head per pass whenever either is
+    // given): column = list slot * block_size + token (…Us2.h:2192-2194,2239-2244,3366-3404).  Scores are kept in
+    // base-2 exponent units here, so the bias is scaled like them; a masked score becomes -1e12 (…Us2.h:860).
+    constexpr float kLog2e = 1.4426950408889634f;
+    constexpr float kMasked = -1.0e12f * kLog2e;
+    const bool biased = NQ == 1 && (p.pse != nullptr || p.amask != nullptr);
+    const int b_of_row = biased ? (int)(row0 / p.Hq) : 0;
+    const long long pse_row = ((long long)(p.pse_b == 1 ? 0 : b_of_row) * p.Hq + (row0 - (long long)b_of_row * p.Hq)) * p.pse_s;
+    const long long mask_row = (long long)b_of_row * p.amask_s;
     while (cur.next(lane)) {
         const int n = cur.n;
         const int phys = __builtin_amdgcn_readfirstlane(list[n].phys);
@@ -805,6 +814,11 @@ __device__ __forceinline__ void stream_valu(const AttnParams& p, const PageEntry
 #pragma unroll
                     for (int e = 0; e < EPL; ++e) acc = fmaf(qf[g][e], kf[e], acc);
                     acc = group_allsum<LPT>(acc);
+                    if (biased && live) {
+                        const long long col = (long long)(n_base + n) * p.block_size + (t0 + i * TPL + grp);
+                        if (p.pse && col < p.pse_s) acc += load_qk_elem(p.pse, p.q_dtype, pse_row + col) * kLog2e;
+                        if (p.amask && col < p.amask_s && p.amask[mask_row + col]) acc = kMasked;
+                    }
                     s[g][i] = live ? acc : -INFINITY;
                 }
             }
@@ -934,7 +948,7 @@ __device__ __forceinline__ void stream_mfma(const AttnParams& p, const PageEntry
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float x = load_qk_elem(p.q, p.q_dtype, (row0 + h) * D + d0 + j) *
-                                    load_qk_elem(p.antiq_scale, p.q_dtype, (long long)n2 * D + d0 + j);
+                                    load_qk_elem(p.antiq_scale, p.q_dtype, p.antiq_per_tensor ? 0 : (long long)n2 * D + d0 + j);
                     hi8[j] = (_Float16)x;
                     lo8[j] = (_Float16)(x - (float)hi8[j]);
                 }
@@ -1317,7 +1331,7 @@ void attn_kernel(const AttnParams p) {
             float v = 0.f;
             if (g < R) {
                 v = load_qk_elem(p.q, p.q_dtype, (row0 + g) * D + d) * qscale;
-                if (QUANT) v *= load_qk_elem(p.antiq_scale, p.q_dtype, (long long)n2 * D + d);
+                if (QUANT) v *= load_qk_elem(p.antiq_scale, p.q_dtype, p.antiq_per_tensor ? 0 : (long long)n2 * D + d);
             }
             qst[t] = v;
         }
@@ -1370,12 +1384,33 @@ void attn_kernel(const AttnParams p) {
     auto store_out = [&](long long row, int d, int n2, float acc, float lt) {
         float r = lt > 0.f ? acc / lt : 0.f;
         if (QUANT && lt > 0.f) {   // (P.V / l + offset_v) * scale_v, …Us2.h:4160-4174
-            const long long pi = (long long)p.Hkv * D + (long long)n2 * D + d;   // value params follow the key params
+            // value params follow the key params (…Us2.h:2035-2043)
+            const long long pi = p.antiq_per_tensor ? 1 : (long long)p.Hkv * D + (long long)n2 * D + d;
             if (p.antiq_offset) r += load_qk_elem(p.antiq_offset, p.q_dtype, pi);
             r *= load_qk_elem(p.antiq_scale, p.q_dtype, pi);
         }
         const long long oi = row * D + d;
-        if (p.out_dtype == kF32) ((float*)p.out)[oi] = r;
+        if (p.out_dtype == kI8) {
+            // int8 output (…Us2.h:4016-4111): out * scale2 + offset2 in fp32 (two roundings), then f32 -> f16 -> int8,
+            // both steps rounding to nearest with ties away from zero (CAST_ROUND) and saturating.
+            const long long qi = p.quant2_per_channel ? (row % p.Hq) * D + d : 0;
+            auto param = [&](const void* t) {
+                return p.quant2_dtype == kBF16 ? (float)((const __bf16*)t)[qi] : ((const float*)t)[qi];
+            };
+            float x = __fmul_rn(r, param(p.quant_scale2));
+            if (p.quant_offset2) x = __fadd_rn(x, param(p.quant_offset2));
+            const float ax = fminf(fabsf(x), 65504.f);
+            // f16 below |x| (round toward zero), then up by one f16 step when the remainder reaches half a step
+            uint16_t hb = __builtin_bit_cast(uint16_t, (_Float16)ax);
+            if ((float)__builtin_bit_cast(_Float16, hb) > ax) --hb;
+            const float lo = (float)__builtin_bit_cast(_Float16, hb);
+            const float hi = (float)__builtin_bit_cast(_Float16, (uint16_t)(hb + 1));
+            const float hx = (hb < 0x7bff && (ax - lo) * 2.f >= (hi - lo)) ? hi : lo;
+            int q8 = (int)floorf(hx + 0.5f);
+            q8 = !(x == x) ? 0 : (x < 0.f ? -q8 : q8);
+            q8 = max(-128, min(127, q8));
+            ((int8_t*)p.out)[oi] = (int8_t)q8;
+        } else if (p.out_dtype == kF32) ((float*)p.out)[oi] = r;
         else if (p.out_dtype == kBF16) ((__bf16*)p.out)[oi] = (__bf16)r;   // round to nearest even (…Us2.h:3476-3477)
         else ((_Float16*)p.out)[oi] = (_Float16)r;
     };
@@ -1429,14 +1464,15 @@ void attn_kernel(const AttnParams p) {
         if (shared) return (float*)(board_data((int)blockIdx.x) + tail_part_off);
         return nullptr;
     };
-    auto run_stream = [&](const PageEntry* list, const float* qst, int slot, PageCursor& cur, int n2, long long row0,
-                          int R) {
+    auto run_stream = [&](const PageEntry* list, int n_base, const float* qst, int slot, PageCursor& cur, int n2,
+                          long long row0, int R) {
         if constexpr (MFMA)
             stream_mfma<KVT, LPT>(p, list, combs + (size_t)slot * kStreamWaves * nq * cstride,
                                   smem + p.off_vst + (size_t)wave * (32 * (D * 2 + 32)), cur, n2, row0, R, nq, qscale,
                                   lane, wave);
         else
-            stream_valu<KVT, NQ, LPT>(p, list, qst, combs + (size_t)slot * kStreamWaves * nq * cstride, cur, n2, lane,
+            stream_valu<KVT, NQ, LPT>(p, list, qst, combs + (size_t)slot * kStreamWaves * nq * cstride, cur, n2, row0,
+                                      n_base, lane,
                                       wave);
         if (cur.mode != 0 && lane == 0 && cur.chunks > 0) {
             atomicAdd(&team[3], cur.chunks);
@@ -1534,7 +1570,7 @@ void attn_kernel(const AttnParams p) {
             if (wave == 0) SPFA_STAMP(8);
             PageCursor cur;
             cur.init(nch > 0 ? 1 : 0, &my_board->state, pc, nch, nU, wave);
-            run_stream(lists + (size_t)slot * p.max_entries + lo, qsts + (size_t)slot * nq * D, slot, cur, n2, row0, R);
+            run_stream(lists + (size_t)slot * p.max_entries + lo, lo, qsts + (size_t)slot * nq * D, slot, cur, n2, row0, R);
             if (wave == 0) SPFA_STAMP(9);
         }
         __syncthreads();
@@ -1648,7 +1684,7 @@ void attn_kernel(const AttnParams p) {
         if (!selector) {
             PageCursor cur;
             cur.init(2, &boards[v].state, th.pc, th.nch, th.nU, wave);
-            run_stream(lists, qsts, 0, cur, th.n2, th.row0, th.R);
+            run_stream(lists, 0, qsts, 0, cur, th.n2, th.row0, th.R);
         }
         __syncthreads();
         const int got = team[3];

@@ -66,6 +66,19 @@ struct AttnParams {
     float scale;
     const void* antiq_scale;   // [2, Hkv*D] in q dtype, or null
     const void* antiq_offset;  // [2, Hkv*D] in q dtype, or null
+    int antiq_per_tensor;      // 1: antiq_scale / antiq_offset are [2] (one key and one value parameter)
+    // Additive score bias and boolean mask over the columns of the gathered sequence (column = list slot * block_size +
+    // token in page), …Us2.h:3366-3404.  Either one makes every q head run as a pass of its own.
+    const void* pse;           // [pse_b, Hq, 1, pse_s] in q dtype, or null
+    int pse_b;                 // 1 (shared by the batch) or B
+    long long pse_s;
+    const unsigned char* amask;// [B, amask_s] bytes, non zero = masked out, or null
+    long long amask_s;
+    // int8 output (…Us2.h:4016-4111): round(out * quant_scale2 + quant_offset2)
+    const void* quant_scale2;  // [1] or [Hq * D], f32 or bf16, or null
+    const void* quant_offset2; // same shape and dtype as quant_scale2, or null
+    int quant2_dtype;          // kF32 | kBF16
+    int quant2_per_channel;    // 1: [Hq * D]
     // mode 0
     const int32_t* block_position; // [B, rows, P]
     int pos_rows;                  // Hq or Hkv

@@ -115,6 +115,14 @@ def _seq_lengths_arg(actual_seq_lengths, device):
     return _abi.to_int_array(actual_seq_lengths), None
 
 
+def _default_out_dtype(query, quant_scale2):
+    """The output has the query's dtype unless an output quantisation scale asks for int8
+    (sparse_paged_fusion_attention_tiling.cc:569-605)."""
+    if isinstance(quant_scale2, torch.Tensor) and quant_scale2.numel() > 0:
+        return torch.int8
+    return query.dtype
+
+
 def sparse_paged_attention(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, pse_shift: torch.Tensor,
                            attention_mask: torch.Tensor, actual_seq_lengths, dequant_scale1: torch.Tensor,
                            quant_scale1: torch.Tensor, dequant_scale2: torch.Tensor, quant_scale2: torch.Tensor,
@@ -125,10 +133,16 @@ def sparse_paged_attention(query: torch.Tensor, key: torch.Tensor, value: torch.
                            *, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
     """Decode attention over the pages listed in blockposition (add_custom.py:41-75; binding
     sparse_paged_attention_impl_npu wraps key/value into one-tensor lists and returns a tensor shaped
-    like query).  out_dtype=torch.float32 (extra) returns the un-rounded result."""
+    like query).  out_dtype=torch.float32 (extra) returns the un-rounded result.
+
+    pse_shift [B | 1, num_heads, 1, S] (query dtype) is added to the scaled scores, attention_mask [B, ..., S]
+    (bool / int8 / uint8, non zero = masked) replaces them by -1e12; both run over the columns of the gathered
+    sequence, list slot * block_size + token.  quant_scale2 / quant_offset2 (float32 or bfloat16; one value or
+    num_heads * D) turn the output into int8.  antiquant_scale / antiquant_offset may be [2, Hkv, D] (per channel)
+    or [2] (per tensor).  dequant_scale1, quant_scale1, dequant_scale2 and kv_padding_size must be empty."""
     _abi.require_gpu(query, key, value, blocktable, blockposition)
     dev = query.device
-    out = torch.empty(query.shape, dtype=out_dtype or query.dtype, device=dev)
+    out = torch.empty(query.shape, dtype=out_dtype or _default_out_dtype(query, quant_scale2), device=dev)
     seq_arr, dev_lengths = _seq_lengths_arg(actual_seq_lengths, dev)
     tens = [_abi.to_acl(t) for t in (query,)]
     kl, vl = _abi.to_acl_list([key]), _abi.to_acl_list([value])
@@ -170,7 +184,7 @@ def sparse_paged_fusion_attention(query: torch.Tensor, key: torch.Tensor, value:
     reference (sparse_paged_fusion_attention.cpp:68) and is ignored."""
     _abi.require_gpu(query, key, value, blocktable, l1_cent, block_ids, total_seq_len)
     dev = query.device
-    out = torch.empty(query.shape, dtype=out_dtype or query.dtype, device=dev)
+    out = torch.empty(query.shape, dtype=out_dtype or _default_out_dtype(query, quant_scale2), device=dev)
     _set_knobs(k, sink_recent, max_pages_cap)
     tens = [_abi.to_acl(query)]
     kl, vl = _abi.to_acl_list([key]), _abi.to_acl_list([value])

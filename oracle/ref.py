@@ -190,7 +190,8 @@ def sparse_paged_attention(q, key_cache, value_cache, block_table, block_positio
                            scale: float, block_size: int, kv_layout: str = "BSH",
                            antiquant_scale=None, antiquant_offset=None,
                            token_limit=None, p_round: str | None = None,
-                           exact: bool = True) -> np.ndarray:
+                           exact: bool = True, pse_shift=None, atten_mask=None,
+                           quant_scale2=None, quant_offset2=None) -> np.ndarray:
     """Decode attention over a virtual sequence of selected pages.  Returns fp32 [B,Hq,D].
 
     Virtual token t of batch b / head row r lives in virtual page j = t // bs; its
@@ -210,7 +211,17 @@ def sparse_paged_attention(q, key_cache, value_cache, block_table, block_positio
                    (:859,4472), P rounded to p_round ('f16' | 'bf16' | None) before P.V.
     int8 KV (…Us2.h:2647,2651,4160-4174): q' = q * scale_k (per channel), key offset
     dropped (softmax is shift invariant), out = (P.V_i8 / l + offset_v) * scale_v.
-    antiquant_scale/offset: [2, Hkv*D] (0 = key, 1 = value; …Us2.h:2035-2043).
+    antiquant_scale/offset: [2, Hkv*D] (0 = key, 1 = value; …Us2.h:2035-2043), or [2]: one
+    key and one value parameter for the whole tensor (:2036-2038).
+
+    pse_shift [B | 1, Hq, 1, S] is added to the scaled scores and atten_mask [B, S]
+    (non zero = masked) then replaces them by -1e12 (…Us2.h:3363-3404, :860); both are
+    indexed by the COLUMN of the gathered sequence, j * block_size + i for token i of the
+    j-th list slot (:2192-2194, 2239-2244).
+
+    quant_scale2 / quant_offset2 (scalar or [Hq * D]): int8 output,
+    out * scale2 + offset2 in fp32, cast to f16 and then to int8, both with ties away from
+    zero (…Us2.h:4016-4111); the result is returned as float32 holding the int8 values.
     """
     q = np.asarray(q, dtype=np.float32)
     B, Hq, D = q.shape
@@ -223,9 +234,16 @@ def sparse_paged_attention(q, key_cache, value_cache, block_table, block_positio
     bt = np.asarray(block_table)
     quant = antiquant_scale is not None
     if quant:
-        a_s = np.asarray(antiquant_scale, dtype=np.float32).reshape(2, Hkv, D)
-        a_o = (np.asarray(antiquant_offset, dtype=np.float32).reshape(2, Hkv, D)
-               if antiquant_offset is not None else None)
+        def _params(t):
+            t = np.asarray(t, dtype=np.float32)
+            if t.size == 2:
+                return np.broadcast_to(t.reshape(2, 1, 1), (2, Hkv, D))
+            return t.reshape(2, Hkv, D)
+        a_s = _params(antiquant_scale)
+        a_o = _params(antiquant_offset) if antiquant_offset is not None else None
+    pse = None if pse_shift is None else np.asarray(pse_shift, dtype=np.float32)
+    amask = None if atten_mask is None else np.asarray(atten_mask).reshape(B, -1)
+    assert (pse is None and amask is None) or exact, "pse_shift / atten_mask: exact mode only"
     out = np.zeros((B, Hq, D), dtype=np.float32)
     facc = np.float64 if exact else np.float32
     for b in range(B):
@@ -242,7 +260,7 @@ def sparse_paged_attention(q, key_cache, value_cache, block_table, block_positio
             qv = q[b, h].astype(facc)
             if quant:
                 qv = qv * a_s[0, n2].astype(facc)
-            ks, vs = [], []
+            ks, vs, cols = [], [], []
             for j in range(n_pages):
                 p = int(row[j])
                 blk = int(bt[b, p])
@@ -253,12 +271,18 @@ def sparse_paged_attention(q, key_cache, value_cache, block_table, block_positio
                     continue
                 ks.append(_kv_rows(key_cache, blk, n2, kv_layout, Hkv, D)[:valid])
                 vs.append(_kv_rows(value_cache, blk, n2, kv_layout, Hkv, D)[:valid])
+                cols.append(j * block_size + np.arange(valid))
             if not ks:
                 continue
             if exact:
                 K = np.concatenate(ks).astype(np.float64)
                 V = np.concatenate(vs).astype(np.float64)
                 s = (K @ qv) * np.float64(scale)
+                col = np.concatenate(cols)
+                if pse is not None:
+                    s = s + pse[b if pse.shape[0] > 1 else 0, h, 0, col].astype(np.float64)
+                if amask is not None:
+                    s = np.where(amask[b, col] != 0, np.float64(-1e12), s)
                 p_ = np.exp(s - s.max())
                 o = (p_ @ V) / p_.sum()
             else:
@@ -283,7 +307,39 @@ def sparse_paged_attention(q, key_cache, value_cache, block_table, block_positio
                     o = o + a_o[1, n2].astype(facc)
                 o = o * a_s[1, n2].astype(facc)
             out[b, h] = o.astype(np.float32)
+    if quant_scale2 is not None:
+        out = post_quant(out, quant_scale2, quant_offset2)
     return out
+
+
+def _round_half_away(x: np.ndarray) -> np.ndarray:
+    return np.sign(x) * np.floor(np.abs(x) + 0.5)
+
+
+def f32_to_f16_half_away(x: np.ndarray) -> np.ndarray:
+    """float32 -> float16 rounding to nearest with ties away from zero (the accelerator's CAST_ROUND)."""
+    x = np.asarray(x, dtype=np.float32)
+    ax = np.minimum(np.abs(x), np.float32(65504))
+    near = ax.astype(np.float16)                         # ties to even
+    below = np.where(near.astype(np.float32) > ax, np.nextafter(near, np.float16(0)), near)
+    with np.errstate(over="ignore"):
+        above = np.nextafter(below, np.float16(np.inf))
+    lo, hi = below.astype(np.float64), above.astype(np.float64)
+    up = np.isfinite(hi) & ((ax.astype(np.float64) - lo) * 2 >= (hi - lo))
+    return np.where(up, above, below).astype(np.float16) * np.sign(x).astype(np.float16)
+
+
+def post_quant(out: np.ndarray, quant_scale2, quant_offset2=None) -> np.ndarray:
+    """int8 output quantisation of attention_out [B, Hq, D] (…Us2.h:4016-4111); float32 holding int8 values."""
+    B, Hq, D = out.shape
+    sc = np.asarray(quant_scale2, dtype=np.float32).reshape(-1)
+    sc = sc.reshape(1, Hq, D) if sc.size > 1 else sc.reshape(1, 1, 1)
+    x = out.astype(np.float32) * sc
+    if quant_offset2 is not None:
+        of = np.asarray(quant_offset2, dtype=np.float32).reshape(-1)
+        x = x + (of.reshape(1, Hq, D) if of.size > 1 else of.reshape(1, 1, 1))
+    h = f32_to_f16_half_away(x.astype(np.float32)).astype(np.float32)
+    return np.clip(_round_half_away(h), -128, 127).astype(np.float32)
 
 
 def sparse_paged_fusion_attention(q, key_cache, value_cache, block_table, l1_cent, block_ids,
@@ -291,7 +347,8 @@ def sparse_paged_fusion_attention(q, key_cache, value_cache, block_table, l1_cen
                                   block_size: int = 128, k: int = 64, max_page_num: int = 256,
                                   sink_recent: bool = False, max_pages_cap: bool = False,
                                   kv_layout: str = "BSH", antiquant_scale=None,
-                                  antiquant_offset=None, p_round=None, exact: bool = True):
+                                  antiquant_offset=None, p_round=None, exact: bool = True,
+                                  pse_shift=None, atten_mask=None, quant_scale2=None, quant_offset2=None):
     """cent_select then attention over each q head's own page list
     (sparse_paged_fusion_attention.cpp:56-76; attention runs with
     actualSeqLengths := max_page_position_length and blockPosition := the rows just
@@ -312,5 +369,7 @@ def sparse_paged_fusion_attention(q, key_cache, value_cache, block_table, l1_cen
     out = sparse_paged_attention(np.asarray(q)[:B], key_cache, value_cache, block_table, eff,
                                  None, num_heads, num_kv_heads, scale, block_size, kv_layout,
                                  antiquant_scale, antiquant_offset,
-                                 token_limit=np.asarray(total_seq_len), p_round=p_round, exact=exact)
+                                 token_limit=np.asarray(total_seq_len), p_round=p_round, exact=exact,
+                                 pse_shift=pse_shift, atten_mask=atten_mask, quant_scale2=quant_scale2,
+                                 quant_offset2=quant_offset2)
     return out, pos, len8, max8

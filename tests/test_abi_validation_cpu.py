@@ -47,7 +47,7 @@ def tlist(lib, t):
 
 
 def attention(lib, *, Hq=8, Hkv=2, D=128, bs=128, B=3, q_dtype=F16, kv_dtype=F16, kv_shape=None, layout=b"BNSD",
-              pos_rows=None, antiq=None, out_dtype=None, pse=None):
+              pos_rows=None, antiq=None, out_dtype=None, pse=None, mask=None, qs2=None, qo2=None):
     q = tensor(lib, (B, Hq, D), q_dtype)
     kv_shape = kv_shape or (40, bs, Hkv, D)
     k, v = tlist(lib, tensor(lib, kv_shape, kv_dtype)), tlist(lib, tensor(lib, kv_shape, kv_dtype))
@@ -56,7 +56,7 @@ def attention(lib, *, Hq=8, Hkv=2, D=128, bs=128, B=3, q_dtype=F16, kv_dtype=F16
     out = tensor(lib, (B, Hq, D), out_dtype if out_dtype is not None else q_dtype)
     ws, ex = c_uint64(0), c_void_p()
     st = lib.aclnnSparsePagedAttentionGetWorkspaceSize(
-        q, k, v, pse, None, None, None, None, None, None, None, antiq, None, table, None, pos,
+        q, k, v, pse, mask, None, None, None, None, qs2, qo2, antiq, None, table, None, pos,
         Hq, 0.088, layout, Hkv, bs, 1, out, ctypes.byref(ws), ctypes.byref(ex))
     if st == 0:
         lib.aclDestroyAclOpExecutor(ex)
@@ -93,9 +93,44 @@ def test_attention_rejects(lib, kw, fragment):
     assert fragment in msg, msg
 
 
+def test_score_bias_mask_and_output_quantisation_operands(lib):
+    """pseShift / attenMask / quantScale2 (…_tiling_check.cc:737-844,412-464, …_tiling.cc:569-650)."""
+    S = 24 * 128                                           # sMax = blocktable columns * blockSize
+    BOOL, U8 = 12, 4
+    assert attention(lib, pse=tensor(lib, (3, 8, 1, S), F16))[0] == 0
+    assert attention(lib, pse=tensor(lib, (1, 8, 1, S + 5), F16), mask=tensor(lib, (3, 1, 1, S), BOOL))[0] == 0
+    assert attention(lib, mask=tensor(lib, (3, S), U8))[0] == 0
+    for kw, fragment in [
+        (dict(pse=tensor(lib, (3, 8, 1, 12), F16)), "less than sMax"),
+        (dict(pse=tensor(lib, (2, 8, 1, S), F16)), "does not match (B, N, 1, S)"),
+        (dict(pse=tensor(lib, (3, 4, 1, S), F16)), "does not match (B, N, 1, S)"),
+        (dict(pse=tensor(lib, (3, 8, 1, S), BF16)), "pseShift dtype"),
+        (dict(pse=tensor(lib, (3, 8, S), F16)), "pseShift must be"),
+        (dict(mask=tensor(lib, (2, S), BOOL)), "attenMask must hold"),
+        (dict(mask=tensor(lib, (3, S - 1), BOOL)), "less than sMax"),
+        (dict(mask=tensor(lib, (3, S), F16)), "attenMask must be bool"),
+        (dict(out_dtype=I8), "quantScale2 is absent"),
+        (dict(qs2=tensor(lib, (1,), F32)), "not int8, but quantScale2"),
+        (dict(out_dtype=I8, qs2=tensor(lib, (1,), F16)), "float32 or bfloat16"),
+        (dict(out_dtype=I8, qs2=tensor(lib, (1,), BF16)), "needs a bfloat16 query"),
+        (dict(out_dtype=I8, qs2=tensor(lib, (8, 64), F32)), "quantScale2 must hold"),
+        (dict(out_dtype=I8, qs2=tensor(lib, (8, 128), F32), qo2=tensor(lib, (1,), F32)), "quantOffset2 must have"),
+        (dict(out_dtype=I8, qs2=tensor(lib, (1,), F32), qo2=tensor(lib, (1,), BF16)), "same dtype"),
+    ]:
+        st, _, msg = attention(lib, **kw)
+        assert st == PARAM_INVALID and fragment in msg, (kw.keys(), msg)
+    assert attention(lib, out_dtype=I8, qs2=tensor(lib, (1,), F32))[0] == 0
+    assert attention(lib, out_dtype=I8, qs2=tensor(lib, (1, 8, 1, 128), F32), qo2=tensor(lib, (1, 8, 1, 128), F32))[0] == 0
+    assert attention(lib, q_dtype=BF16, kv_dtype=BF16, out_dtype=I8, qs2=tensor(lib, (8 * 128,), BF16))[0] == 0
+    # antiquant parameters: per channel [2, Hkv, D] (any spelling with that many values) or per tensor [2]
+    kv8 = dict(kv_dtype=I8)
+    assert attention(lib, antiq=tensor(lib, (2,), F16), **kv8)[0] == 0
+    assert attention(lib, antiq=tensor(lib, (2, 2 * 128), F16), **kv8)[0] == 0
+    st, _, msg = attention(lib, antiq=tensor(lib, (2, 1), F16), **kv8)
+    assert st == PARAM_INVALID and "antiquantScale" in msg
+
+
 def test_unsupported_operands_and_null_pointers(lib):
-    st, _, msg = attention(lib, pse=tensor(lib, (3, 8, 1, 12), F16))
-    assert st == PARAM_INVALID and "pseShift" in msg
     st, _, msg = attention(lib, antiq=tensor(lib, (2, 2, 128), F16))
     assert st == PARAM_INVALID and "antiquant" in msg
     ws, ex = c_uint64(0), c_void_p()
