@@ -9,10 +9,23 @@
  * query [B,Hq,D] | [B,Hq,1,D] | [B,1,Hq*D], f16|bf16.  key/value: one-tensor lists holding the paged
  * cache, [blocks,bs,Hkv*D] / [blocks,bs,Hkv,D] (BSH) or [blocks,Hkv,bs,D] (BNSD); dtype of query, or
  * int8 together with antiquantScale (+ optional antiquantOffset), each [2,Hkv,1,D] | [2,Hkv,D] | [2,Hkv*D]
- * in the query dtype, index 0 = key, 1 = value.  blocktable [>=B,maxBlocks] i32.
+ * (per channel) or [2] (per tensor) in the query dtype, index 0 = key, 1 = value.
+ * blocktable [>=B,maxBlocks] i32.
  * blockposition [B,Hq|Hkv,P] i32, a row ends at its first 0x7fffffff.  actualSeqLengths: host int64,
- * 1 or B values (NULL: the whole list).  attentionOut: query's shape; dtype of query (or float32).
- * pseShift, attenMask, dequant/quantScale*, quantOffset2, kvPaddingSize must be NULL (not on this path).
+ * 1 or B values (NULL: the whole list).  attentionOut: query's shape; dtype of query (or float32), or int8
+ * together with quantScale2.
+ *
+ * Optional operands of the attention core (NULL or an empty tensor = absent):
+ *   pseShift   [B|1, Hq, 1, S] in the query dtype, S >= maxBlocks*blockSize: added to the scaled scores
+ *              (sparse_paged_fusion_attention_tiling_check.cc:737-803; kernel …_split_Bbn2s2_Us2.h:3366-3380);
+ *   attenMask  [B, ..., S] bool | int8 | uint8, one row of S >= maxBlocks*blockSize flags per batch: a non-zero
+ *              flag replaces the score by -1e12 (…_tiling_check.cc:805-844; kernel :3382-3404, :860).
+ *              Both index the COLUMNS of the gathered sequence: list slot * blockSize + token (:2192-2194,
+ *              2239-2244).  With either one present every q head is streamed as a pass of its own;
+ *   quantScale2 / quantOffset2  float32 (or bfloat16 with a bfloat16 query), 1 value or Hq*D values
+ *              ([1,Hq,1,D] and the other spellings of …_tiling_check.cc:412-464): attentionOut is int8,
+ *              round(out * scale2 + offset2) through float16, ties away from zero, saturating (kernel :4016-4111).
+ * dequantScale1, quantScale1, dequantScale2 (int8 queries) and kvPaddingSize must be NULL: not on this path.
  */
 #ifndef SPFA_ACLNN_SPARSE_PAGED_ATTENTION_H_
 #define SPFA_ACLNN_SPARSE_PAGED_ATTENTION_H_
