@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--cpu-sample-batch", type=int, default=8)
     ap.add_argument("--seed", type=int, default=2024)
     ap.add_argument("--no-tail-sharing", action="store_true", help="diagnostic: spfaSetTailSharing(0)")
+    ap.add_argument("--force-tail-sharing", action="store_true", help="diagnostic: spfaSetTailSharing(2)")
     ap.add_argument("--no-shared-scoring", action="store_true", help="diagnostic: spfaSetSharedScoring(0)")
     return ap.parse_args()
 
@@ -218,6 +219,9 @@ def main():
     if a.no_tail_sharing:
         from custom_ops import _abi
         _abi.spfaSetTailSharing(0)
+    if a.force_tail_sharing:
+        from custom_ops import _abi
+        _abi.spfaSetTailSharing(2)
     if a.no_shared_scoring:
         from custom_ops import _abi
         _abi.spfaSetSharedScoring(0)

@@ -256,7 +256,7 @@ aclnnStatus spfaSetMaxSplit(int64_t max_split) {
     g_max_split = (int)max_split;
     return ACLNN_SUCCESS;
 }
-aclnnStatus spfaSetTailSharing(int enable) { g_tail_sharing = enable ? 1 : 0; return ACLNN_SUCCESS; }
+aclnnStatus spfaSetTailSharing(int enable) { g_tail_sharing = enable < 0 ? 0 : (enable > 2 ? 2 : enable); return ACLNN_SUCCESS; }
 aclnnStatus spfaSetSharedScoring(int enable) { g_shared_scoring = enable ? 1 : 0; return ACLNN_SUCCESS; }
 aclnnStatus spfaSetPageSize(int64_t page_size) {
     if (page_size < 1 || page_size > 512) return fail(ACLNN_ERR_PARAM_INVALID, "page size %lld out of [1, 512]", (long long)page_size);
@@ -625,21 +625,23 @@ static size_t carve_lds(spfa::AttnParams& p, size_t nq) {
     p.off_keys = (int)off;
     if (p.mode == 1) off += align16(nq * p.Cp * 4);                        // score keys (selector wave)
     p.off_cbits = (int)off;
+    const size_t max_waves = 8;   // upper bound of the waves of a workgroup (streamers + selectors)
     if (p.mode == 1)   // top-k cluster bitmaps (one per wave that selects a row of the first item) + 16 row lengths
-        off += align16((nq < 6 ? nq : 6) * (size_t)(p.Cp / 32) * 4) + 64;
+        off += align16((nq < max_waves ? nq : max_waves) * (size_t)(p.Cp / 32) * 4) + 64;
     p.off_pbits = (int)off;
     if (p.mode == 1) off += align16(nq * ((p.max_page + 63) / 64) * 8);    // per-head page bitmaps
     p.off_list = (int)off;
     off += align16((size_t)2 * p.max_entries * 8);                         // double-buffered page lists
     p.off_comb = (int)off;
-    off += align16((size_t)2 * 4 * nq * (p.D + 2) * 4);                    // streamer states of two items
-    p.off_qst = (int)off;
     const bool mfma = spfa::attention_uses_mfma((int)nq, p.kv_dtype, p.D);
+    const size_t sw = (size_t)spfa::attention_stream_waves(mfma);
+    off += align16((size_t)2 * sw * nq * (p.D + 2) * 4);                   // streamer states of two items
+    p.off_qst = (int)off;
     if (!mfma) off += align16((size_t)2 * nq * p.D * 4);                   // pre-scaled q rows (VALU streamer)
     p.off_hdr = (int)off;
     off += 2 * 48 + 16;                                                    // two item headers + 4 workgroup words
     p.off_vst = (int)off;
-    if (mfma) off += (size_t)4 * 32 * (p.D * 2 + 32);                      // V tile images of the 4 streamer waves
+    if (mfma) off += sw * 32 * (p.D * 2 + 32);                             // V tile images of the streamer waves
     return off;
 }
 
@@ -687,12 +689,14 @@ static void plan_workspace(aclOpExecutor* e) {
     // workgroup (at most two per CU): header, page list, q rows of the VALU streamer, 17 states.
     // The protocol costs about 10 us per workgroup (claims, one more state to merge); it pays when a workgroup has
     // several items to be out of step by, or long ones.
-    const bool worth = items >= 6ll * n_cu || (items > n_cu && p.max_entries >= 512);
-    p.tail_on = (g_tail_sharing && p.n_split == 1 && n_cu > 0 && worth) ? 1 : 0;
-    const uint64_t n_boards = p.tail_on ? 2ull * n_cu : 0;
+    // Group passes (MFMA streamer) run one workgroup per CU with a few long, unequal items each (the union of a
+    // group's lists varies from item to item): measured 2.4 % faster with sharing at 2 items per workgroup.
     const bool mfma = spfa::attention_uses_mfma(p.rows_per_pass, p.kv_dtype, p.D);
+    const bool worth = items >= 6ll * n_cu || (items > n_cu && (p.max_entries >= 512 || mfma));
+    p.tail_on = (g_tail_sharing && p.n_split == 1 && n_cu > 0 && (worth || g_tail_sharing == 2)) ? 1 : 0;
+    const uint64_t n_boards = p.tail_on ? 2ull * n_cu : 0;
     const uint64_t state_bytes = (uint64_t)p.rows_per_pass * (p.D + 2) * 4;
-    p.tail_chunks = p.rows_per_pass == 1 ? 32 : 16;   // one state per chunk + the owner's: keep the wide ones fewer
+    p.tail_chunks = p.rows_per_pass <= 4 ? 32 : 16;   // one state per chunk + the owner's: keep the wide ones fewer
     p.tail_stride = (long long)up256(32 + (uint64_t)p.max_entries * 8 + (mfma ? 0 : (uint64_t)p.rows_per_pass * p.D * 4) + 16 +
                                      (uint64_t)(p.tail_chunks + 1) * state_bytes);
     // Shared first scoring (fused op with a page-list split): the workgroups of one item score its rows together.

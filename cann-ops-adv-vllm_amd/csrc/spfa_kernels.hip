@@ -531,7 +531,7 @@ struct ItemHdr {              // 40 bytes in LDS (a 48-byte slot)
     int R;                    // q heads in the pass
     int lo;                   // first list entry of this workgroup's share (page-list split, else 0)
     int next;                 // the item this workgroup handles after this one (claimed one item ahead), < 0: none
-    int pc, nch;              // > 0: the workgroup's last item, shared in nch chunks of pc pages (see TailBoard)
+    int pc, nch;              // > 0: the workgroup's last item, shared in nch chunks (pc: tail_geometry; see TailBoard)
 };
 
 template <typename KVT> struct KvTraits;
@@ -614,11 +614,18 @@ __device__ __forceinline__ void merge_state(float& m, float& l, float* o, int n,
 #else
 #define SPFA_STAMP(slotidx) do {} while (0)
 #endif
-constexpr int kStreamWaves = 4;
+#ifndef SPFA_MFMA_STREAMERS
+#define SPFA_MFMA_STREAMERS 4 // streamer waves of the MFMA kernels (one workgroup per CU fits: 241 VGPRs, LDS)
+#endif
+// Streamer waves per workgroup.  The one-q-head kernels run two workgroups per CU (8 streamers per CU).
+constexpr int stream_waves(bool mfma) { return mfma ? SPFA_MFMA_STREAMERS : 4; }
 // Selector waves per workgroup: one where a single q head is selected per item; two where a pass carries a
 // whole GQA group (several rows to select for one page stream), so that selection stays hidden behind the stream.
-constexpr int sel_waves(bool mfma) { return mfma ? 2 : 1; }
-constexpr int attn_threads(bool mfma) { return 64 * (kStreamWaves + sel_waves(mfma)); }
+#ifndef SPFA_MFMA_SELECTORS
+#define SPFA_MFMA_SELECTORS 2
+#endif
+constexpr int sel_waves(bool mfma) { return mfma ? SPFA_MFMA_SELECTORS : 1; }
+constexpr int attn_threads(bool mfma) { return 64 * (stream_waves(mfma) + sel_waves(mfma)); }
 
 // Pull the next work item.  Class c holds items c, c+8, ...; start with this XCD's class.
 // The first item of every workgroup is static (item = blockIdx.x, which is the (blockIdx.x / 8)-th item of
@@ -680,21 +687,39 @@ struct TailBoard {           // 16 bytes per workgroup, zeroed before every laun
                              // a helper party left its state in slot 1 + c (c = the lowest chunk it took)
 };
 struct TailHdr {             // 32 bytes at the start of a board's data area, written before the board is offered
-    int nU, pc, nch;         // list length, pages per chunk, chunks
+    int nU, pc, nch;         // list length, chunk geometry (tail_geometry), chunks
     int n2, row0, R, b, pad;
 };
 constexpr int kHdrSlot = 48;                        // bytes per ItemHdr slot in LDS
 constexpr int kTailChunksMax = 32;                  // chunks per shared item (AttnParams::tail_chunks <= this)
 
+// Chunks of a shared item: the first nbig chunks hold pc pages each, the rest ps <= pc pages.  The owner claims from
+// the front, where a claim (which drains the wave's loads in flight) buys a long run of pages; the back, where the
+// helpers arrive and where the owner's waves finish, is cut finely: about the last third of the list goes into half
+// of the chunks, so what one party still holds when everything is claimed is a small fraction of the item.
+// Returns pc | ps << 12 | nbig << 24 and the chunk count (<= max_chunks <= 32); list lengths stay below 4096.
+__device__ __forceinline__ int tail_geometry(int nU, int max_chunks, int min_pc, int& nch) {
+    if (nU <= max_chunks) { nch = nU; return 1 | (1 << 12); }
+    const int ns = max_chunks / 2;
+    const int ps = max(1, (nU / 3 + ns - 1) / ns);
+    const int big_pages = nU - ns * ps;
+    const int pc = max(min_pc, (big_pages + (max_chunks - ns) - 1) / (max_chunks - ns));
+    const int nbig = min((big_pages + pc - 1) / pc, nU / pc);
+    nch = nbig + (nU - nbig * pc + ps - 1) / ps;
+    return pc | (ps << 12) | (nbig << 24);
+}
+
 // Page cursor of one streamer wave: static striding (wave, wave + 4, ...) or chunk claims from a board.
 struct PageCursor {
     unsigned* state;   // board word (modes 1, 2)
     int mode;          // 0: static, 1: owner (front), 2: helper (back)
-    int pc, nch, nU;
+    int pc, ps, nbig, nch, nU;     // chunk geometry, see tail_geometry()
     int n, n_end, chunks, first;   // first: lowest chunk claimed
-    __device__ __forceinline__ void init(int mode_, unsigned* state_, int pc_, int nch_, int nU_, int wave) {
-        mode = mode_; state = state_; pc = pc_; nch = nch_; nU = nU_;
-        n = mode_ == 0 ? wave - kStreamWaves : 0; n_end = 0; chunks = 0; first = 1 << 20;
+    int stride;                    // streamer waves of the workgroup (static striding)
+    __device__ __forceinline__ void init(int mode_, unsigned* state_, int geom, int nch_, int nU_, int wave, int stride_) {
+        mode = mode_; state = state_; nch = nch_; nU = nU_; stride = stride_;
+        pc = geom & 0xfff; ps = (geom >> 12) & 0xfff; nbig = geom >> 24;
+        n = mode_ == 0 ? wave - stride_ : 0; n_end = 0; chunks = 0; first = 1 << 20;
     }
     __device__ __forceinline__ int claim(int lane) {
         int c = -1;
@@ -716,14 +741,14 @@ struct PageCursor {
     }
     // advance to the next page of this wave; false when there is none
     __device__ __forceinline__ bool next(int lane) {
-        if (mode == 0) { n += kStreamWaves; return n < nU; }
+        if (mode == 0) { n += stride; return n < nU; }
         if (++n < n_end) return true;
         const int c = claim(lane);
         if (c < 0) return false;
         ++chunks;
         first = min(first, c);
-        n = c * pc;
-        n_end = min(nU, n + pc);
+        n = c < nbig ? c * pc : nbig * pc + (c - nbig) * ps;
+        n_end = min(nU, n + (c < nbig ? pc : ps));
         return n < n_end;
     }
 };
@@ -1136,6 +1161,7 @@ template <typename KVT, int NQ, int LPT, bool MFMA>
 __global__ __launch_bounds__(attn_threads(MFMA), (MFMA ? 2 : (NQ == 1 ? SPFA_MINWAVES : (NQ <= 4 ? SPFA_MINWAVES_N : 1))))
 void attn_kernel(const AttnParams p) {
     constexpr int SW = sel_waves(MFMA);           // selector team size
+    constexpr int kStreamWaves = stream_waves(MFMA);
     constexpr int WAVES = kStreamWaves + SW;
     constexpr bool QUANT = sizeof(KVT) == 1;
     constexpr float kNegBig = -1.0e30f;
@@ -1343,8 +1369,7 @@ void attn_kernel(const AttnParams p) {
         if (p.tail_on && nxt < 0 && nU > 0) {
             // last item: publish the list (and the q rows of the VALU streamer) and offer it in chunks
             // a claim drains the wave's loads in flight: keep the chunks of the wide (MFMA) streamer a few pages long
-            pc = max((nU + p.tail_chunks - 1) / p.tail_chunks, MFMA ? SPFA_TAIL_MIN_PAGES : 1);
-            nch = (nU + pc - 1) / pc;
+            pc = tail_geometry(nU, p.tail_chunks, MFMA ? SPFA_TAIL_MIN_PAGES : 1, nch);
             char* bd = board_data((int)blockIdx.x);
             unsigned long long* glist = (unsigned long long*)(bd + tail_list_off);
             wave_lds_sync();
@@ -1569,7 +1594,7 @@ void attn_kernel(const AttnParams p) {
         else {
             if (wave == 0) SPFA_STAMP(8);
             PageCursor cur;
-            cur.init(nch > 0 ? 1 : 0, &my_board->state, pc, nch, nU, wave);
+            cur.init(nch > 0 ? 1 : 0, &my_board->state, pc, nch, nU, wave, kStreamWaves);
             run_stream(lists + (size_t)slot * p.max_entries + lo, lo, qsts + (size_t)slot * nq * D, slot, cur, n2, row0, R);
             if (wave == 0) SPFA_STAMP(9);
         }
@@ -1683,7 +1708,7 @@ void attn_kernel(const AttnParams p) {
         __syncthreads();   // the copies are complete, and everybody has read team[2] before it is reused
         if (!selector) {
             PageCursor cur;
-            cur.init(2, &boards[v].state, th.pc, th.nch, th.nU, wave);
+            cur.init(2, &boards[v].state, th.pc, th.nch, th.nU, wave, kStreamWaves);
             run_stream(lists, 0, qsts, 0, cur, th.n2, th.row0, th.R);
         }
         __syncthreads();
@@ -1788,6 +1813,8 @@ int device_cu_count() {
 bool attention_uses_mfma(int rows_per_pass, int kv_dtype, int D) {
     return rows_per_pass > 1 && !(kv_dtype == kI8 && D > 256);
 }
+
+int attention_stream_waves(bool mfma) { return stream_waves(mfma); }
 
 int attention_rows_per_pass(int G, int kv_dtype, int D) {
     if (G <= 1) return 1;

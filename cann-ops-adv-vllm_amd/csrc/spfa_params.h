@@ -127,5 +127,7 @@ int device_cu_count();
 // (which stages V tiles in LDS: 4 waves x 32 rows x (2 D + 32) bytes at off_vst).
 int attention_rows_per_pass(int G, int kv_dtype, int D);
 bool attention_uses_mfma(int rows_per_pass, int kv_dtype, int D);
+// Streamer waves per workgroup of the two kernel forms (sizes the state and V-tile areas in LDS).
+int attention_stream_waves(bool mfma);
 
 }  // namespace spfa

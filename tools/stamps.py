@@ -14,6 +14,8 @@ import custom_ops  # noqa: E402
 from custom_ops import _abi  # noqa: E402
 
 a = bench.parse()
+if a.force_tail_sharing:
+    _abi.spfaSetTailSharing(2)
 dev = torch.device("cuda", 0)
 wl = bench.build_workload(a, dev, a.batch, a.seed, custom_ops)
 B, Hq, Hkv, D, bs = a.batch, a.heads, a.kv_heads, a.head_dim, a.block_size
