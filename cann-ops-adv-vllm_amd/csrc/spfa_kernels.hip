@@ -1261,6 +1261,7 @@ void attn_kernel(const AttnParams p) {
     // 2 the rows' page lists are done as well (bitmaps in pbits_all, lengths in row_lens)
     // raw_next: the value of fetch_begin when the caller has issued it already (first item), else kNoFetch
     constexpr unsigned kNoFetch = 0xfffffffeu;
+    int fetch_round = 0;   // claims made by this workgroup so far
     auto build = [&](int slot, int item, int stage, unsigned raw_next) {
         ItemHdr* hdr = hdr_at(slot);
         PageEntry* list = lists + (size_t)slot * p.max_entries;
@@ -1273,8 +1274,10 @@ void attn_kernel(const AttnParams p) {
         // claim the item after this one now (the leader; the answer is needed at the end): whether this is the
         // workgroup's last item must be known before it is streamed
         const bool dynamic = total > (int)gridDim.x;
+        // class whose queue this claim tries first: the own XCD's, or (class_step = 1) one class further per claim
+        const int cls = (xcd + p.class_step * (++fetch_round)) & 7;
         if (raw_next == kNoFetch && dynamic && sidx == 0)
-            raw_next = fetch_begin(p.counters, xcd, total, (int)gridDim.x, lane);
+            raw_next = fetch_begin(p.counters, cls, total, (int)gridDim.x, lane);
         const ItemCtx ctx = decode(item);
         const int b = ctx.b, n2 = ctx.n2, head0 = ctx.head0, R = ctx.R;
         const long long row0 = ctx.row0;
@@ -1362,7 +1365,7 @@ void attn_kernel(const AttnParams p) {
             qst[t] = v;
         }
         SPFA_STAMP(6);
-        const int nxt = dynamic ? fetch_end(raw_next, p.counters, xcd, total, (int)gridDim.x, lane) : -1;
+        const int nxt = dynamic ? fetch_end(raw_next, p.counters, cls, total, (int)gridDim.x, lane) : -1;
         SPFA_STAMP(1);
         nU = min(nU, p.max_entries);
         int pc = 0, nch = 0;
@@ -1517,7 +1520,7 @@ void attn_kernel(const AttnParams p) {
         int stage0 = 1;
         unsigned raw0 = kNoFetch;
         if (wave == kStreamWaves && total > (int)gridDim.x)
-            raw0 = fetch_begin(p.counters, xcd, total, (int)gridDim.x, lane);
+            raw0 = fetch_begin(p.counters, (xcd + p.class_step) & 7, total, (int)gridDim.x, lane);
         if (p.mode == 1) {
             const ItemCtx c0 = decode(item0);
             // Page-list split: the NS workgroups of an item all need the very same rows.  Each scores every NS-th

@@ -96,6 +96,10 @@ struct AttnParams {
     int rows_per_pass;             // q heads of a group handled per pass
     int max_entries;               // capacity of the per-workgroup page list
     unsigned* counters;            // 8 work counters (workspace), zeroed before every launch
+    // 0: a workgroup claims items of its own XCD's class (item % 8) as long as there are any, so the kv heads an XCD
+    // works on stay the same (centroids in its L2); 1: every claim starts one class further, which mixes heads whose
+    // page lists are systematically longer or shorter over all XCDs
+    int class_step;
     // page-list split for small batches: n_split workgroups per item (1: off)
     int n_split;
     // sharing of every workgroup's last item (n_split == 1 only): boards and their data areas in the workspace
