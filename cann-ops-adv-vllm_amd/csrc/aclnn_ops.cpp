@@ -137,11 +137,11 @@ int to_dtype(aclDataType t) {
 
 int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
-// q rows scored per centroid pass by the standalone scoring ops: the keys [rows][Cp] u32 must fit a 64 KiB budget
-// (two workgroups per CU), at most 16 rows (one MFMA tile).  When a whole group fits, rows of several sequences
-// share the pass.
+// q rows scored per centroid pass by the standalone scoring ops: the keys [rows][Cp] u32 and the waves' centroid
+// tiles must fit 76 KiB (two workgroups per CU, a few KiB left for the selection scratch), at most 16 rows (one MFMA
+// tile).  When a whole group fits, rows of several sequences share the pass.
 void plan_cent_rows(spfa::CentParams& p) {
-    int r = (64 * 1024) / (p.Cp * 4);
+    int r = (76 * 1024 - spfa::cent_stage_bytes(p.D)) / (p.Cp * 4);
     if (r < 1) r = 1;
     if (r > 16) r = 16;
     if (p.G >= r) {                 // the group alone fills (or exceeds) a pass
@@ -301,7 +301,7 @@ aclnnStatus aclnnComputeCentGetWorkspaceSize(const aclTensor* query, const aclTe
     p.indices = (int32_t*)data_ptr(indicesOut);
     int npow2 = 64;
     while (npow2 < k) npow2 <<= 1;
-    p.lds_bytes = (size_t)p.rows_per_pass * p.Cp * 4 + (size_t)4 * npow2 * 8;
+    p.lds_bytes = (size_t)p.rows_per_pass * p.Cp * 4 + (size_t)4 * npow2 * 8 + (size_t)spfa::cent_stage_bytes(p.D);
     *workspaceSize = 0;
     *executor = e;
     return ACLNN_SUCCESS;
@@ -418,7 +418,7 @@ aclnnStatus aclnnCentSelectGetWorkspaceSize(const aclTensor* query, const aclTen
     p.page_position = (int32_t*)data_ptr(pagePositionOut);
     p.page_position_length = (int32_t*)data_ptr(pagePositionLengthOut);
     p.max_page_position_length = (unsigned long long*)data_ptr(maxPagePositionLengthOut);
-    p.lds_bytes = (size_t)p.rows_per_pass * p.Cp * 4 + (size_t)4 * (p.Cp / 32) * 4;
+    p.lds_bytes = (size_t)p.rows_per_pass * p.Cp * 4 + (size_t)4 * (p.Cp / 32) * 4 + (size_t)spfa::cent_stage_bytes(p.D);
     *workspaceSize = 0;
     *executor = e;
     return ACLNN_SUCCESS;
@@ -642,6 +642,8 @@ static size_t carve_lds(spfa::AttnParams& p, size_t nq) {
     off += 2 * 48 + 16;                                                    // two item headers + 4 workgroup words
     p.off_vst = (int)off;
     if (mfma) off += sw * 32 * (p.D * 2 + 32);                             // V tile images of the streamer waves
+    p.off_stage = (int)off;
+    if (p.mode == 1) off += (size_t)spfa::attention_stage_bytes(mfma, p.D);   // centroid tiles of the scoring waves
     return off;
 }
 

@@ -106,15 +106,41 @@ __device__ __forceinline__ float load_qk_elem(const void* p, int dtype, long lon
 // same heads of the next sequence b_stride rows further (rpb = R: all rows consecutive).
 // The WAVES waves of a workgroup share the tiles; with nparts > 1 the workgroup is one of nparts that share them (it
 // takes every nparts-th group of tiles) and the keys go to global memory with agent-scope stores.
+//
+// The operand layout of the matrix core wants, per load instruction, 16 bytes of 16 DIFFERENT centroid rows in the
+// 16 lanes of a quarter wave: 64 cache lines per instruction, which the CU's address unit works through one line at
+// a time (measured: the pass of one workgroup over 512 KiB of centroids took 34 us with two workgroups per CU,
+// almost all of it address processing).  So the tiles are read the way they lie in memory, 1 KiB contiguous per
+// instruction, parked in a wave-private LDS tile (rows padded by 16 B: the transposed read is conflict free) and
+// read back in the operand layout.  `stage` is that tile: score_stage_bytes(D) bytes per wave.
+#ifndef SPFA_SCORE_LDS
+#define SPFA_SCORE_LDS 1
+#endif
+constexpr int score_stage_bytes(int D) { return SPFA_SCORE_LDS ? 16 * (D * 2 + 16) : 0; }
+__device__ __forceinline__ void wave_order() {   // program order of this wave's LDS accesses (no instruction)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <int WAVES, bool BF16, int KS>
 __device__ __forceinline__ void score_rows_impl(const void* q, const void* cent, long long q_row0, int n2, int R,
-                                                int C, int Cp, uint32_t* keys, int wave, int rpb, int b_stride,
-                                                int part, int nparts) {
+                                                int C, int Cp, uint32_t* keys, char* stage, int wave, int rpb,
+                                                int b_stride, int part, int nparts) {
     constexpr int D = KS * 32;
     constexpr int TG = 16 / KS;   // tiles per group: TG * KS = 16 loads in flight
     const int lane = lane_id();
     const int col = lane & 15;   // A: q row of the tile, B: centroid of the tile
     const int kq = lane >> 4;    // which 8-wide slice of the 32-deep k step
+#if SPFA_SCORE_LDS
+    constexpr int RB = D * 2, RSB = RB + 16;   // bytes of a centroid row, in memory and in the LDS tile
+    constexpr int LPR = RB / 16;               // lanes that read one row
+    constexpr int RPI = 64 / LPR;              // rows per load instruction (KS instructions per 16-row tile)
+    const int lrow = lane / LPR, lpiece = lane % LPR;
+    const char* chead = (const char*)cent + (long long)n2 * C * D * 2 + lpiece * 16;
+    char* st_w = stage + lrow * RSB + lpiece * 16;
+    const char* st_r = stage + col * RSB + kq * 16;
+#endif
     uint4 qa[KS];
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
@@ -123,18 +149,40 @@ __device__ __forceinline__ void score_rows_impl(const void* q, const void* cent,
             qa[kk] = *(const uint4*)((const char*)q +
                                      ((q_row0 + (long long)(col / rpb) * b_stride + col % rpb) * D + kk * 32 + kq * 8) * 2);
     }
+#if !SPFA_SCORE_LDS
     const char* cbase = (const char*)cent + (long long)n2 * C * D * 2 + kq * 16;
+#endif
     const int ntiles = Cp >> 4;   // Cp % 128 == 0: a multiple of every TG
     for (int t0 = (part * WAVES + wave) * TG; t0 < ntiles; t0 += nparts * WAVES * TG) {
         uint4 bv[TG][KS];
+#if SPFA_SCORE_LDS
+#pragma unroll
+        for (int j = 0; j < TG; ++j) {
+#pragma unroll
+            for (int m = 0; m < KS; ++m) {
+                const int c = min((t0 + j) * 16 + m * RPI + lrow, C - 1);
+                bv[j][m] = *(const uint4*)(chead + (long long)c * RB);
+            }
+        }
+#else
 #pragma unroll
         for (int j = 0; j < TG; ++j) {
             const int c = min((t0 + j) * 16 + col, C - 1);
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk) bv[j][kk] = *(const uint4*)(cbase + ((long long)c * D + kk * 32) * 2);
         }
+#endif
 #pragma unroll
         for (int j = 0; j < TG; ++j) {
+#if SPFA_SCORE_LDS
+            // memory order -> operand order through the wave's LDS tile (LDS accesses of a wave execute in order)
+#pragma unroll
+            for (int m = 0; m < KS; ++m) *(uint4*)(st_w + m * RPI * RSB) = bv[j][m];
+            wave_order();
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) bv[j][kk] = *(const uint4*)(st_r + kk * 64);
+            wave_order();
+#endif
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk) {
@@ -163,14 +211,14 @@ __device__ __forceinline__ void score_rows_impl(const void* q, const void* cent,
 // widx: this wave's index among the WAVES waves that share the tiles.
 template <int WAVES>
 __device__ __forceinline__ void score_rows(const void* q, const void* cent, int dtype, long long q_row0,
-                                           int n2, int R, int D, int C, int Cp, uint32_t* keys, int widx,
+                                           int n2, int R, int D, int C, int Cp, uint32_t* keys, char* stage, int widx,
                                            int rpb = 16, int b_stride = 0, int part = 0, int nparts = 1) {
 #define SPFA_SCORE(KS)                                                                              \
     case KS:                                                                                        \
         if (dtype == kBF16)                                                                           \
-            score_rows_impl<WAVES, true, KS>(q, cent, q_row0, n2, R, C, Cp, keys, widx, rpb, b_stride, part, nparts);  \
+            score_rows_impl<WAVES, true, KS>(q, cent, q_row0, n2, R, C, Cp, keys, stage, widx, rpb, b_stride, part, nparts);  \
         else                                                                                          \
-            score_rows_impl<WAVES, false, KS>(q, cent, q_row0, n2, R, C, Cp, keys, widx, rpb, b_stride, part, nparts); \
+            score_rows_impl<WAVES, false, KS>(q, cent, q_row0, n2, R, C, Cp, keys, stage, widx, rpb, b_stride, part, nparts); \
         break;
     switch (D >> 5) {
         SPFA_SCORE(1)
@@ -432,7 +480,8 @@ __global__ __launch_bounds__(kThreads) void cent_kernel(const CentParams p) {
         const int Rg = min(RG, p.G - g0);                              // heads of this pass (per sequence)
         const int R = nb * Rg;
         const long long row0 = (long long)b0 * p.Hq + (long long)n2 * p.G + g0;
-        score_rows<4>(p.q, p.cent, p.qk_dtype, row0, n2, R, p.D, p.C, p.Cp, keys, wave, nb > 1 ? rpb : R, p.Hq);
+        score_rows<4>(p.q, p.cent, p.qk_dtype, row0, n2, R, p.D, p.C, p.Cp, keys,
+                      smem + p.lds_bytes - (size_t)(4 - wave) * score_stage_bytes(p.D), wave, nb > 1 ? rpb : R, p.Hq);
         __syncthreads();
         for (int r = wave; r < R; r += 4) {
             const int b = b0 + (nb > 1 ? r / rpb : 0);
@@ -1191,6 +1240,12 @@ void attn_kernel(const AttnParams p) {
     ItemHdr* hdrs = (ItemHdr*)(smem + p.off_hdr);                                 // [2]
     int* team = (int*)(smem + p.off_hdr + 2 * kHdrSlot);   // [0] selector team counter, [1] lowest chunk, [2] flag, [3] chunks
     auto hdr_at = [&](int slot) { return (ItemHdr*)((char*)hdrs + slot * kHdrSlot); };
+    // LDS tile of wave w for the centroid pass: the MFMA streamers lend their V tile area (only the first item is
+    // scored by them, before anything is streamed), everybody else has a tile at off_stage
+    auto stage_of = [&](int w) -> char* {
+        if (MFMA && w < kStreamWaves) return smem + p.off_vst + (size_t)w * (32 * (D * 2 + 32));
+        return smem + p.off_stage + (size_t)(MFMA ? w - kStreamWaves : w) * score_stage_bytes(D);
+    };
     TailBoard* boards = (TailBoard*)p.tail_boards;
     TailBoard* my_board = boards + blockIdx.x;
     auto board_data = [&](int v) { return p.tail_data + (size_t)v * p.tail_stride; };
@@ -1286,7 +1341,7 @@ void attn_kernel(const AttnParams p) {
         if (p.mode == 1) {
             const int seq = p.seq_len[b];
             const int page_len = page_len_of(b);
-            if (stage < 1) score_rows<SW>(p.q, p.cent, p.q_dtype, row0, n2, R, D, p.C, p.Cp, keys, sidx);
+            if (stage < 1) score_rows<SW>(p.q, p.cent, p.q_dtype, row0, n2, R, D, p.C, p.Cp, keys, stage_of(wave), sidx);
             team_sync();
             SPFA_STAMP(2);
             if (stage < 2) {
@@ -1531,7 +1586,7 @@ void attn_kernel(const AttnParams p) {
             if (p.pg_on && NS > 1) {
                 const int gid = item0 / NS;
                 uint32_t* gkeys = p.pg_keys + (size_t)gid * 16 * p.Cp;
-                score_rows<WAVES>(p.q, p.cent, p.q_dtype, c0.row0, c0.n2, c0.R, D, p.C, p.Cp, gkeys, wave, c0.R, 0,
+                score_rows<WAVES>(p.q, p.cent, p.q_dtype, c0.row0, c0.n2, c0.R, D, p.C, p.Cp, gkeys, stage_of(wave), wave, c0.R, 0,
                                   c0.split, NS);
                 wait_stores();
                 __syncthreads();
@@ -1552,7 +1607,7 @@ void attn_kernel(const AttnParams p) {
                 __syncthreads();
             }
             if (!have_keys) {
-                score_rows<WAVES>(p.q, p.cent, p.q_dtype, c0.row0, c0.n2, c0.R, D, p.C, p.Cp, keys, wave);
+                score_rows<WAVES>(p.q, p.cent, p.q_dtype, c0.row0, c0.n2, c0.R, D, p.C, p.Cp, keys, stage_of(wave), wave);
                 __syncthreads();
             }
             if (wave == 0) SPFA_STAMP(12);
@@ -1818,6 +1873,10 @@ bool attention_uses_mfma(int rows_per_pass, int kv_dtype, int D) {
 }
 
 int attention_stream_waves(bool mfma) { return stream_waves(mfma); }
+int attention_stage_bytes(bool mfma, int D) {
+    return (mfma ? sel_waves(true) : stream_waves(false) + sel_waves(false)) * score_stage_bytes(D);
+}
+int cent_stage_bytes(int D) { return 4 * score_stage_bytes(D); }
 
 int attention_rows_per_pass(int G, int kv_dtype, int D) {
     if (G <= 1) return 1;

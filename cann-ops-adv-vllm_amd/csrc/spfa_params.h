@@ -116,7 +116,7 @@ struct AttnParams {
     float* split_partials;         // [items * n_split][rows_per_pass][D + 2] un-normalised states (workspace)
     unsigned long long* debug;     // diagnostic builds only: [grid][16 items][16 stamps], else null
     // LDS carve (bytes from the dynamic base)
-    int off_keys, off_cbits, off_pbits, off_list, off_comb, off_qst, off_hdr, off_vst;
+    int off_keys, off_cbits, off_pbits, off_list, off_comb, off_qst, off_hdr, off_vst, off_stage;
     size_t lds_bytes;
 };
 
@@ -133,5 +133,9 @@ int attention_rows_per_pass(int G, int kv_dtype, int D);
 bool attention_uses_mfma(int rows_per_pass, int kv_dtype, int D);
 // Streamer waves per workgroup of the two kernel forms (sizes the state and V-tile areas in LDS).
 int attention_stream_waves(bool mfma);
+// LDS tiles through which the centroid pass turns memory order into matrix-core operand order: bytes at off_stage of
+// the attention kernels, and at the end of the dynamic LDS of the cent kernels.
+int attention_stage_bytes(bool mfma, int D);
+int cent_stage_bytes(int D);
 
 }  // namespace spfa
