@@ -634,7 +634,7 @@ static size_t carve_lds(spfa::AttnParams& p, size_t nq) {
     off += align16((size_t)2 * p.max_entries * 8);                         // double-buffered page lists
     p.off_comb = (int)off;
     const bool mfma = spfa::attention_uses_mfma((int)nq, p.kv_dtype, p.D);
-    const size_t sw = (size_t)spfa::attention_stream_waves(mfma);
+    const size_t sw = (size_t)spfa::attention_stream_waves(mfma, p.kv_dtype);
     off += align16((size_t)2 * sw * nq * (p.D + 2) * 4);                   // streamer states of two items
     p.off_qst = (int)off;
     if (!mfma) off += align16((size_t)2 * nq * p.D * 4);                   // pre-scaled q rows (VALU streamer)

@@ -642,6 +642,9 @@ __device__ __forceinline__ void merge_state(float& m, float& l, float* o, int n,
 #define SPFA_MFMA_PREFETCH 0 // MFMA streamer: 1 = issue the next tile's loads before computing the current one.  Costs
                              // 64 VGPRs, which pushes the selector's top-k keys into scratch: measured slower.
 #endif
+#ifndef SPFA_MFMA_PREFETCH_I8
+#define SPFA_MFMA_PREFETCH_I8 0
+#endif
 #ifndef SPFA_PRIO
 #define SPFA_PRIO 0          // wave priority of the streamer waves in the item loop (selector stays at 0)
 #endif
@@ -667,14 +670,18 @@ __device__ __forceinline__ void merge_state(float& m, float& l, float* o, int n,
 #define SPFA_MFMA_STREAMERS 4 // streamer waves of the MFMA kernels (one workgroup per CU fits: 241 VGPRs, LDS)
 #endif
 // Streamer waves per workgroup.  The one-q-head kernels run two workgroups per CU (8 streamers per CU).
-constexpr int stream_waves(bool mfma) { return mfma ? SPFA_MFMA_STREAMERS : 4; }
+#ifndef SPFA_MFMA_STREAMERS_I8
+#define SPFA_MFMA_STREAMERS_I8 6 // int8 tiles are half the bytes: more waves to keep as many bytes in flight (measured
+                                 // on GQA 32/8, S=64k: 0.292 -> 0.275 ms; register prefetch instead: slower)
+#endif
+constexpr int stream_waves(bool mfma, bool i8) { return mfma ? (i8 ? SPFA_MFMA_STREAMERS_I8 : SPFA_MFMA_STREAMERS) : 4; }
 // Selector waves per workgroup: one where a single q head is selected per item; two where a pass carries a
 // whole GQA group (several rows to select for one page stream), so that selection stays hidden behind the stream.
 #ifndef SPFA_MFMA_SELECTORS
 #define SPFA_MFMA_SELECTORS 2
 #endif
 constexpr int sel_waves(bool mfma) { return mfma ? SPFA_MFMA_SELECTORS : 1; }
-constexpr int attn_threads(bool mfma) { return 64 * (stream_waves(mfma) + sel_waves(mfma)); }
+constexpr int attn_threads(bool mfma, bool i8) { return 64 * (stream_waves(mfma, i8) + sel_waves(mfma)); }
 
 // Pull the next work item.  Class c holds items c, c+8, ...; start with this XCD's class.
 // The first item of every workgroup is static (item = blockIdx.x, which is the (blockIdx.x / 8)-th item of
@@ -986,7 +993,7 @@ __device__ __forceinline__ void stream_mfma(const AttnParams& p, const PageEntry
     constexpr int TPL = 64 / LPT;               // V rows per wave load
     constexpr int VL = 32 / TPL;                // V wave loads per tile
     constexpr int RS = D * 2 + 32;              // LDS row stride of the (16-bit) V image
-    constexpr bool PREFETCH = SPFA_MFMA_PREFETCH && LPT <= 16;   // two tiles of registers fit
+    constexpr bool PREFETCH = (I8 ? SPFA_MFMA_PREFETCH_I8 : SPFA_MFMA_PREFETCH) && LPT <= 16;   // two tiles of registers fit
     constexpr float kNegBig = -1.0e30f;
     typedef short short4v __attribute__((ext_vector_type(4)));
     typedef _Float16 half2v __attribute__((ext_vector_type(2)));
@@ -1207,10 +1214,10 @@ __device__ __forceinline__ void stream_mfma(const AttnParams& p, const PageEntry
 
 // NQ: q heads per pass of the VALU streamer (register arrays); the MFMA streamer takes p.rows_per_pass (<= 16).
 template <typename KVT, int NQ, int LPT, bool MFMA>
-__global__ __launch_bounds__(attn_threads(MFMA), (MFMA ? 2 : (NQ == 1 ? SPFA_MINWAVES : (NQ <= 4 ? SPFA_MINWAVES_N : 1))))
+__global__ __launch_bounds__(attn_threads(MFMA, sizeof(KVT) == 1), (MFMA ? 2 : (NQ == 1 ? SPFA_MINWAVES : (NQ <= 4 ? SPFA_MINWAVES_N : 1))))
 void attn_kernel(const AttnParams p) {
     constexpr int SW = sel_waves(MFMA);           // selector team size
-    constexpr int kStreamWaves = stream_waves(MFMA);
+    constexpr int kStreamWaves = stream_waves(MFMA, sizeof(KVT) == 1);
     constexpr int WAVES = kStreamWaves + SW;
     constexpr bool QUANT = sizeof(KVT) == 1;
     constexpr float kNegBig = -1.0e30f;
@@ -1804,7 +1811,7 @@ hipError_t launch_attn_one(const AttnParams& p, hipStream_t s, long long* cap_ou
     int occ = 0;
     const int n_cu = device_cu_count();
     if (n_cu <= 0) return hipErrorNoDevice;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, attn_threads(MFMA), p.lds_bytes);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, attn_threads(MFMA, sizeof(KVT) == 1), p.lds_bytes);
     if (e != hipSuccess) return e;
     int blocks_per_cu = occ < 1 ? 1 : occ;   // residency of the persistent grid
     // 8 streamer waves per CU already saturate HBM; a third workgroup only deepens the memory queues
@@ -1824,7 +1831,7 @@ hipError_t launch_attn_one(const AttnParams& p, hipStream_t s, long long* cap_ou
         fprintf(stderr, "[spfa] attn grid=%u blocks/CU=%d CUs=%d lds=%zu items=%lld mfma=%d\n", grid.x, blocks_per_cu, n_cu,
                 p.lds_bytes, total, (int)MFMA);
     }
-    hipLaunchKernelGGL(kern, grid, dim3(attn_threads(MFMA)), p.lds_bytes, s, p);
+    hipLaunchKernelGGL(kern, grid, dim3(attn_threads(MFMA, sizeof(KVT) == 1)), p.lds_bytes, s, p);
     return hipGetLastError();
 }
 
@@ -1872,9 +1879,9 @@ bool attention_uses_mfma(int rows_per_pass, int kv_dtype, int D) {
     return rows_per_pass > 1 && !(kv_dtype == kI8 && D > 256);
 }
 
-int attention_stream_waves(bool mfma) { return stream_waves(mfma); }
+int attention_stream_waves(bool mfma, int kv_dtype) { return stream_waves(mfma, kv_dtype == kI8); }
 int attention_stage_bytes(bool mfma, int D) {
-    return (mfma ? sel_waves(true) : stream_waves(false) + sel_waves(false)) * score_stage_bytes(D);
+    return (mfma ? sel_waves(true) : stream_waves(false, false) + sel_waves(false)) * score_stage_bytes(D);
 }
 int cent_stage_bytes(int D) { return 4 * score_stage_bytes(D); }
 

@@ -132,7 +132,7 @@ int device_cu_count();
 int attention_rows_per_pass(int G, int kv_dtype, int D);
 bool attention_uses_mfma(int rows_per_pass, int kv_dtype, int D);
 // Streamer waves per workgroup of the two kernel forms (sizes the state and V-tile areas in LDS).
-int attention_stream_waves(bool mfma);
+int attention_stream_waves(bool mfma, int kv_dtype);
 // LDS tiles through which the centroid pass turns memory order into matrix-core operand order: bytes at off_stage of
 // the attention kernels, and at the end of the dynamic LDS of the cent kernels.
 int attention_stage_bytes(bool mfma, int D);

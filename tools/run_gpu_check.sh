@@ -11,6 +11,8 @@ run
 run
 run --kv-heads 8
 run --kv-heads 8 --seqlen 131072 --topk 64
+run --kv int8 --seqlen 65536
+run --kv-heads 8 --kv int8 --seqlen 65536
 if [ "$1" = "small" ]; then
   run --batch 1
   run --batch 8
