@@ -138,10 +138,14 @@ int to_dtype(aclDataType t) {
 int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 // q rows scored per centroid pass by the standalone scoring ops: the keys [rows][Cp] u32 and the waves' centroid
-// tiles must fit 76 KiB (two workgroups per CU, a few KiB left for the selection scratch), at most 16 rows (one MFMA
-// tile).  When a whole group fits, rows of several sequences share the pass.
+// tiles share an 84 KiB budget (8 rows at C = 2048, D = 128; measured faster than 7 rows with two workgroups per
+// CU), at most 16 rows (one MFMA tile).  When a whole group fits, rows of several sequences share the pass, dealt
+// evenly over the workgroups of a kv head.
 void plan_cent_rows(spfa::CentParams& p) {
-    int r = (76 * 1024 - spfa::cent_stage_bytes(p.D)) / (p.Cp * 4);
+#ifndef SPFA_CENT_BUDGET_KB
+#define SPFA_CENT_BUDGET_KB 84
+#endif
+    int r = (SPFA_CENT_BUDGET_KB * 1024 - spfa::cent_stage_bytes(p.D)) / (p.Cp * 4);
     if (r < 1) r = 1;
     if (r > 16) r = 16;
     if (p.G >= r) {                 // the group alone fills (or exceeds) a pass
@@ -150,6 +154,16 @@ void plan_cent_rows(spfa::CentParams& p) {
     } else {
         p.seq_per_group = r / p.G;
         if (p.seq_per_group > p.B) p.seq_per_group = p.B > 0 ? p.B : 1;
+        // a small launch is latency bound: rather one workgroup per CU re-reading centroids from L2 than a few
+        // workgroups that each serve many sequences
+        const int n_cu = spfa::device_cu_count();
+        if (n_cu > 0 && p.Hkv > 0) {
+            const int groups_wanted = (n_cu + p.Hkv - 1) / p.Hkv;
+            const int cap = p.B / groups_wanted > 1 ? p.B / groups_wanted : 1;
+            if (p.seq_per_group > cap) p.seq_per_group = cap;
+        }
+        const int groups = (p.B + p.seq_per_group - 1) / p.seq_per_group;   // same number of passes, equal sizes
+        if (groups > 0) p.seq_per_group = (p.B + groups - 1) / groups;
         p.rows_per_pass = p.seq_per_group * p.G;
     }
 }

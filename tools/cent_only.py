@@ -18,4 +18,13 @@ for _ in range(a.steps):
     custom_ops.cent_select(wl["q"], wl["l1"], wl["block_ids"], wl["table"], wl["seq"], k=a.topk)
     custom_ops.compute_cent(wl["q"], wl["l1"], k=a.topk)
 torch.cuda.synchronize()
+for name, fn in (("cent_select", lambda: custom_ops.cent_select(wl["q"], wl["l1"], wl["block_ids"], wl["table"], wl["seq"], k=a.topk)),
+                 ("compute_cent", lambda: custom_ops.compute_cent(wl["q"], wl["l1"], k=a.topk))):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"{name}: {e0.elapsed_time(e1) / 50 * 1e3:.1f} us per call (launch included, back to back)")
 print("done")
