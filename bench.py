@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--topk", type=int, default=32)
     ap.add_argument("--block-size", type=int, default=128)
     ap.add_argument("--kv", choices=["f16", "bf16", "int8"], default="f16")
+    ap.add_argument("--kv-layout", choices=["bsh", "bnsd"], default="bsh",
+                    help="bsh = [blocks, block_size, Hkv, D] (the reference's layout, the default); bnsd = [blocks, Hkv, "
+                         "block_size, D] (a head's rows of a page are contiguous)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-batch", type=int, default=8)
     ap.add_argument("--seed", type=int, default=2024)
@@ -67,10 +70,11 @@ def build_workload(a, device, B, seed, custom_ops):
     n_pages = B * page_len
     qdt = torch.bfloat16 if a.kv == "bf16" else torch.float16
     eps = 1e-3
+    kv_shape = (n_pages, bs, Hkv, D) if a.kv_layout == "bsh" else (n_pages, Hkv, bs, D)
     q = (torch.rand((B, Hq, D), generator=g, device=device) * (1 - eps) + eps).to(qdt)
     l1 = torch.randn((Hkv, C, D), generator=g, device=device).to(qdt)
     if a.kv == "int8":
-        key = torch.empty((n_pages, bs, Hkv, D), dtype=torch.int8, device=device)
+        key = torch.empty(kv_shape, dtype=torch.int8, device=device)
         val = torch.empty_like(key)
         step = max(1, (1 << 30) // (bs * Hkv * D))
         for i in range(0, n_pages, step):
@@ -79,7 +83,7 @@ def build_workload(a, device, B, seed, custom_ops):
         a_scale = (torch.rand((2, Hkv, D), generator=g, device=device) * 0.02 + 0.001).to(qdt)
         a_off = torch.randn((2, Hkv, D), generator=g, device=device).to(qdt)
     else:
-        key = torch.empty((n_pages, bs, Hkv, D), dtype=qdt, device=device)
+        key = torch.empty(kv_shape, dtype=qdt, device=device)
         val = torch.empty_like(key)
         step = max(1, (1 << 30) // (bs * Hkv * D * 2))
         for i in range(0, n_pages, step):
@@ -287,7 +291,7 @@ def main():
         "config": {"workload": workload_name(a),
                    "batch_per_gpu": B, "global_batch": world * B, "heads": Hq, "kv_heads": Hkv, "head_dim": D,
                    "seq_len": a.seqlen, "clusters": a.clusters, "topk": a.topk, "block_size": bs, "kv_dtype": a.kv,
-                   "kv_layout": "BSH [blocks, block_size, Hkv, D]", "kv_pool_GiB": round(2 * wl["key"].numel() * kv_elem / 2 ** 30, 2),
+                   "kv_layout": ("BSH [blocks, block_size, Hkv, D]" if a.kv_layout == "bsh" else "BNSD [blocks, Hkv, block_size, D]"), "kv_pool_GiB": round(2 * wl["key"].numel() * kv_elem / 2 ** 30, 2),
                    "pages_selected_per_launch": pages, "parallelism": f"batch-shard x{world}"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": kernel_ms,
