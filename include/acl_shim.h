@@ -100,7 +100,9 @@ SPFA_API aclnnStatus spfaSetPageCap(int enable);
 SPFA_API aclnnStatus spfaSetMaxSplit(int64_t maxSplit);
 /* Launches with several items per workgroup: the last item of every workgroup is streamed in chunks that
  * workgroups which ran out of work may take over (states merged in the same launch; workspace grows by one data
- * area per resident workgroup).  0 turns it off.  Default on. */
+ * area per resident workgroup).  0: off (bit-reproducible attentionOut); 1 (default): on where the planner expects
+ * it to pay (several items per workgroup, long lists, group passes); 2: on for every launch without a page-list
+ * split. */
 SPFA_API aclnnStatus spfaSetTailSharing(int enable);
 /* Fused op with a page-list split: the workgroups of one item score its rows in one shared pass over the centroids
  * and exchange the score keys through the workspace (a bounded wait; a workgroup that gives up scores alone).
