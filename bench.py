@@ -70,7 +70,7 @@ def build_workload(a, device, B, seed, custom_ops):
     n_pages = B * page_len
     qdt = torch.bfloat16 if a.kv == "bf16" else torch.float16
     eps = 1e-3
-    kv_shape = (n_pages, bs, Hkv, D) if a.kv_layout == "bsh" else (n_pages, Hkv, bs, D)
+    kv_shape = (n_pages, bs, Hkv, D) if getattr(a, "kv_layout", "bsh") == "bsh" else (n_pages, Hkv, bs, D)
     q = (torch.rand((B, Hq, D), generator=g, device=device) * (1 - eps) + eps).to(qdt)
     l1 = torch.randn((Hkv, C, D), generator=g, device=device).to(qdt)
     if a.kv == "int8":

@@ -179,7 +179,7 @@ aclnnStatus check_qcent(const aclTensor* query, const aclTensor* l1, int* Hq, in
     *C = (int)l1->dims[1];
     *D = (int)l1->dims[2];
     REQUIRE(*Hkv > 0 && *C > 0, "l1_cent is empty");
-    REQUIRE(*D == 32 || *D == 64 || *D == 128 || *D == 256, "head dim %d: must be 32, 64, 128 or 256", *D);
+    REQUIRE(*D == 32 || *D == 64 || *D == 128 || *D == 256 || *D == 512, "head dim %d: must be 32, 64, 128, 256 or 512", *D);
     REQUIRE(*C <= 16384, "cluster count %d exceeds 16384", *C);
     (void)Hq;
     return ACLNN_SUCCESS;
@@ -515,8 +515,8 @@ static aclnnStatus plan_attention(spfa::AttnParams& p, const aclTensor* query, c
         return fail(ACLNN_ERR_PARAM_INVALID, "KV cache must be [blocks,bs,Hkv*D], [blocks,bs,Hkv,D] or [blocks,Hkv,bs,D]");
     }
     const int lpt = D * es / 16;
-    REQUIRE((D * es) % 16 == 0 && (lpt == 4 || lpt == 8 || lpt == 16 || lpt == 32),
-            "head dim %d with %d-byte KV elements is not supported (row bytes must be 64, 128, 256 or 512)", D, es);
+    REQUIRE((D * es) % 16 == 0 && (lpt == 4 || lpt == 8 || lpt == 16 || lpt == 32 || (lpt == 64 && !quant)),
+            "head dim %d with %d-byte KV elements is not supported (row bytes must be 64, 128, 256, 512 or 1024)", D, es);
     REQUIRE(kd[0] > 0 && kd[0] <= 0x7fffffff, "KV cache has no blocks");
 
     if (quant) {

@@ -78,6 +78,7 @@ __device__ __forceinline__ float dpp(float x) {
 // Sum over the LPT consecutive lanes that share one token; every lane of the group gets the sum.
 template <int LPT>
 __device__ __forceinline__ float group_allsum(float x) {
+    if constexpr (LPT >= 64) x += __shfl_xor(x, 32);
     if constexpr (LPT >= 32) x += __shfl_xor(x, 16);
     if constexpr (LPT >= 16) { x += dpp<0x128>(x); x += dpp<0x124>(x); }   // row_ror 8, 4
     else if constexpr (LPT == 8) x += dpp<0x141>(x);                       // row_half_mirror
@@ -225,10 +226,24 @@ __device__ __forceinline__ void score_rows(const void* q, const void* cent, int 
         SPFA_SCORE(2)
         SPFA_SCORE(4)
         SPFA_SCORE(8)
+        SPFA_SCORE(16)
     }
 #undef SPFA_SCORE
 }
 
+
+// The same with the head dim known at compile time (the attention kernels: one D per instantiation).  QDT: kF16 / kBF16
+// when the query dtype follows from the KV dtype, -1 when it has to be looked up (int8 KV).
+template <int WAVES, int D, int QDT>
+__device__ __forceinline__ void score_rows_fixed(const void* q, const void* cent, int dtype, long long q_row0, int n2,
+                                                 int R, int C, int Cp, uint32_t* keys, char* stage, int widx,
+                                                 int rpb = 16, int b_stride = 0, int part = 0, int nparts = 1) {
+    constexpr int KS = D / 32;
+    if (QDT == kBF16 || (QDT < 0 && dtype == kBF16))
+        score_rows_impl<WAVES, true, KS>(q, cent, q_row0, n2, R, C, Cp, keys, stage, widx, rpb, b_stride, part, nparts);
+    else
+        score_rows_impl<WAVES, false, KS>(q, cent, q_row0, n2, R, C, Cp, keys, stage, widx, rpb, b_stride, part, nparts);
+}
 
 template <int CTRL>
 __device__ __forceinline__ int dpp_i(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, true); }
@@ -1220,6 +1235,8 @@ void attn_kernel(const AttnParams p) {
     constexpr int kStreamWaves = stream_waves(MFMA, sizeof(KVT) == 1);
     constexpr int WAVES = kStreamWaves + SW;
     constexpr bool QUANT = sizeof(KVT) == 1;
+    constexpr int DC = LPT * 16 / (int)sizeof(KVT);   // head dim of this instantiation (== p.D)
+    constexpr int QDT = QUANT ? -1 : (__is_same(KVT, __bf16) ? (int)kBF16 : (int)kF16);
     constexpr float kNegBig = -1.0e30f;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = lane_id(), wave = wave_id();
@@ -1348,7 +1365,8 @@ void attn_kernel(const AttnParams p) {
         if (p.mode == 1) {
             const int seq = p.seq_len[b];
             const int page_len = page_len_of(b);
-            if (stage < 1) score_rows<SW>(p.q, p.cent, p.q_dtype, row0, n2, R, D, p.C, p.Cp, keys, stage_of(wave), sidx);
+            if (stage < 1)
+                score_rows_fixed<SW, DC, QDT>(p.q, p.cent, p.q_dtype, row0, n2, R, p.C, p.Cp, keys, stage_of(wave), sidx);
             team_sync();
             SPFA_STAMP(2);
             if (stage < 2) {
@@ -1593,7 +1611,7 @@ void attn_kernel(const AttnParams p) {
             if (p.pg_on && NS > 1) {
                 const int gid = item0 / NS;
                 uint32_t* gkeys = p.pg_keys + (size_t)gid * 16 * p.Cp;
-                score_rows<WAVES>(p.q, p.cent, p.q_dtype, c0.row0, c0.n2, c0.R, D, p.C, p.Cp, gkeys, stage_of(wave), wave, c0.R, 0,
+                score_rows_fixed<WAVES, DC, QDT>(p.q, p.cent, p.q_dtype, c0.row0, c0.n2, c0.R, p.C, p.Cp, gkeys, stage_of(wave), wave, c0.R, 0,
                                   c0.split, NS);
                 wait_stores();
                 __syncthreads();
@@ -1614,7 +1632,7 @@ void attn_kernel(const AttnParams p) {
                 __syncthreads();
             }
             if (!have_keys) {
-                score_rows<WAVES>(p.q, p.cent, p.q_dtype, c0.row0, c0.n2, c0.R, D, p.C, p.Cp, keys, stage_of(wave), wave);
+                score_rows_fixed<WAVES, DC, QDT>(p.q, p.cent, p.q_dtype, c0.row0, c0.n2, c0.R, p.C, p.Cp, keys, stage_of(wave), wave);
                 __syncthreads();
             }
             if (wave == 0) SPFA_STAMP(12);
@@ -1843,6 +1861,9 @@ hipError_t launch_attn_valu(const AttnParams& p, int lpt, hipStream_t s, long lo
         case 4: return launch_attn_one<KVT, NQ, 4, false>(p, s, cap_out);
         case 8: return launch_attn_one<KVT, NQ, 8, false>(p, s, cap_out);
         case 32: return launch_attn_one<KVT, NQ, 32, false>(p, s, cap_out);
+        case 64:   // 1024-byte head rows: f16 / bf16 at D = 512 (int8 rows end at 512 bytes)
+            if constexpr (sizeof(KVT) == 2 && NQ == 1) return launch_attn_one<KVT, NQ, 64, false>(p, s, cap_out);
+            break;
 #endif
         case 16: return launch_attn_one<KVT, NQ, 16, false>(p, s, cap_out);
     }
@@ -1874,9 +1895,10 @@ int device_cu_count() {
     return n;
 }
 
-// int8 KV with 512-byte head rows would need 128 accumulator registers for O^T: that shape stays on the VALU form.
+// Head dims above 256 would need 128 and more accumulator registers for O^T: those shapes stay on the VALU form
+// (int8: 4 q heads per pass; f16 / bf16 at D = 512: one).
 bool attention_uses_mfma(int rows_per_pass, int kv_dtype, int D) {
-    return rows_per_pass > 1 && !(kv_dtype == kI8 && D > 256);
+    return rows_per_pass > 1 && D <= 256;
 }
 
 int attention_stream_waves(bool mfma, int kv_dtype) { return stream_waves(mfma, kv_dtype == kI8); }
@@ -1887,6 +1909,7 @@ int cent_stage_bytes(int D) { return 4 * score_stage_bytes(D); }
 
 int attention_rows_per_pass(int G, int kv_dtype, int D) {
     if (G <= 1) return 1;
+    if (kv_dtype != kI8 && D > 256) return 1;   // 1024-byte rows: a wave load is one token row
     if (kv_dtype == kI8 && D > 256) return 4;   // VALU streamer: int8 rows cost 16 accumulators each
     return G < 16 ? G : 16;                     // MFMA streamer: up to 16 columns
 }

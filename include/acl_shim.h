@@ -94,7 +94,7 @@ SPFA_API void ReleaseHugeMem(void* arg, bool sync);
 SPFA_API aclnnStatus spfaSetTopK(int64_t k);
 SPFA_API aclnnStatus spfaSetSinkRecent(int enable);
 SPFA_API aclnnStatus spfaSetPageCap(int enable);
-/* Small batches (fewer items than half the compute units): the two attention ops deal each item's page list to up
+/* Small batches (fewer items than half the workgroups the chip holds at once): the two attention ops deal each item's page list to up
  * to maxSplit workgroups and merge their states in the same launch; the reported workspace size grows by the
  * states.  1 turns the split off.  Default 16, range [1, 16]. */
 SPFA_API aclnnStatus spfaSetMaxSplit(int64_t maxSplit);

@@ -86,6 +86,8 @@ def test_attention_plans_without_a_device(lib):
     (dict(kv_shape=(40, 128, 2, 64)), "KV cache must be"),
     (dict(out_dtype=I32), "attentionOut dtype"),
     (dict(D=80, kv_shape=(40, 128, 2, 80)), "head dim"),
+    (dict(D=512, kv_dtype=I8, kv_shape=(40, 128, 2, 512)), "int8 KV cache needs"),   # the shape itself is accepted
+    (dict(D=1024, kv_shape=(40, 128, 2, 1024)), "head dim"),
 ])
 def test_attention_rejects(lib, kw, fragment):
     st, _, msg = attention(lib, **kw)

@@ -90,6 +90,8 @@ def _random_lists(rng, B, rows, max_page, P, lo, hi):
     ("bf16", "BSH", 32, 1, "kv", 128, 128, "device"),    # G = 32: two passes of 16 heads
     ("f16", "BNSD", 4, 2, "kv", 32, 16, "ragged"),       # G = 2, D = 32
     ("bf16", "BSH", 10, 2, "kv", 256, 32, "none"),       # G = 5, D = 256
+    ("f16", "BSH", 4, 2, "kv", 512, 32, "ragged"),       # D = 512: 1 KiB head rows, one q head per pass
+    ("bf16", "BNSD", 2, 2, "q", 512, 16, "device"),
 ])
 def test_attention_vs_oracle(H, dtype, layout, Hq, Hkv, rows, D, bs, seq_mode):
     rng = datagen.rng_for(1234 + Hq * 7 + D)

@@ -120,5 +120,5 @@ def test_abi_errors(ops):
         ops.compute_cent(q, l1)                      # k > C
     with pytest.raises(AclError, match="dtype"):
         ops.compute_cent(q, l1.to(torch.bfloat16), k=8)
-    with pytest.raises(AclError, match="must be 32, 64, 128 or 256"):
+    with pytest.raises(AclError, match="must be 32, 64, 128, 256 or 512"):
         ops.compute_cent(dev(np.zeros((2, 8, 48), np.float16)), dev(np.zeros((2, 32, 48), np.float16)), k=8)
