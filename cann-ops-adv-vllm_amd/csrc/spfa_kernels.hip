@@ -153,7 +153,7 @@ __device__ __forceinline__ void score_rows_impl(const void* q, const void* cent,
 #if !SPFA_SCORE_LDS
     const char* cbase = (const char*)cent + (long long)n2 * C * D * 2 + kq * 16;
 #endif
-    const int ntiles = Cp >> 4;   // Cp % 128 == 0: a multiple of every TG
+    const int ntiles = Cp >> 4;   // Cp % 128 == 0: a multiple of every TG but the 16 of D = 32 (guarded at the store)
     for (int t0 = (part * WAVES + wave) * TG; t0 < ntiles; t0 += nparts * WAVES * TG) {
         uint4 bv[TG][KS];
 #if SPFA_SCORE_LDS
@@ -199,7 +199,7 @@ __device__ __forceinline__ void score_rows_impl(const void* q, const void* cent,
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int qr = kq * 4 + r;
-                if (qr < R) {
+                if (qr < R && c < Cp) {   // a group of TG tiles may reach past the row (D = 32: 16 tiles, Cp % 128 == 0)
                     const uint32_t key = (c < C) ? score_key(acc[r]) : 0u;
                     if (nparts > 1) st_agent(keys + qr * Cp + c, key);
                     else keys[qr * Cp + c] = key;

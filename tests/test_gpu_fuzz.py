@@ -1,0 +1,155 @@
+"""Seeded sweep over random small shapes: every draw runs the fused op and the separate ops through the C-ABI and
+compares with the oracle — page_position / lengths bit-exact, attention_out within 1e-3 relative.
+
+The reference's tests fix their shapes (tests/cent_select.py:16-28, fused_ifa_v5_case.py:20-61); this sweep walks the
+corners between them: group sizes 1..16, every supported head dim and KV dtype, block sizes 16..256, cluster counts
+that are not multiples of the tile sizes, top-k from 1 to C, ragged lengths down to one token.  Inputs lie on the
+exact grid (datagen.cent_case) so that scores are exact in fp32 and ties are broken the same way on both sides
+(ascending cluster id).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import datagen
+import parity
+from oracle import ref
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def _draw(seed):
+    rng = datagen.rng_for(9000 + seed)
+    kv = ["f16", "bf16", "i8"][seed % 3]
+    D = int(rng.choice([32, 64, 128, 128, 256, 512])) if kv != "i8" else int(rng.choice([64, 128, 128, 256]))
+    G = int(rng.choice([1, 1, 2, 3, 4, 8, 16]))
+    Hkv = int(rng.choice([1, 2, 3, 8])) if G > 1 else int(rng.choice([1, 4, 8, 9]))
+    if G * Hkv > 32:
+        Hkv = max(1, 32 // G)
+    bs = int(rng.choice([32, 64, 128, 256])) if kv == "i8" else int(rng.choice([16, 32, 48, 128, 256]))
+    C = int(rng.choice([16, 100, 129, 256, 640, 1000]))
+    k = int(rng.choice([1, 2, 7, 8, 16, min(64, C), C]))
+    k = min(k, C)
+    B = int(rng.integers(1, 6))
+    max_page = int(rng.integers(3, 40))
+    seq_lens = [int(rng.integers(1, max_page * bs + 1)) for _ in range(B)]
+    seq_lens[int(rng.integers(0, B))] = max_page * bs            # one sequence fills its table
+    return dict(kv=kv, D=D, G=G, Hkv=Hkv, Hq=G * Hkv, bs=bs, C=C, k=k, B=B, max_page=max_page, seq_lens=seq_lens,
+                sink_recent=bool(seed % 5 == 0), cap=bool(seed % 7 == 0), q_extra=int(seed % 2))
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SPFA_FUZZ_SEEDS", "120"))))
+def test_random_shape(seed):
+    import custom_ops
+    import gpu_helpers as H
+    c = _draw(seed)
+    B, Hq, Hkv, D, C, bs, k = c["B"], c["Hq"], c["Hkv"], c["D"], c["C"], c["bs"], c["k"]
+    kv_page_len = c["max_page"] * B + 5
+    q, l1 = datagen.cent_case(seed, B + c["q_extra"], Hq, Hkv, D, C, grid=True)
+    ids, table, seq = datagen.page_case(seed, Hkv, C, kv_page_len, B + 1, c["max_page"], c["seq_lens"])
+    kc, vc = datagen.kv_case(seed, kv_page_len, bs, Hkv, D, "BSH", dist="randn", dtype="i8" if c["kv"] == "i8" else "f16")
+    tdt = torch.bfloat16 if c["kv"] == "bf16" else torch.float16
+    if c["kv"] == "bf16":
+        kc, vc = (ref.round_to_bf16(x.astype(np.float32)) for x in (kc, vc))
+    kw, okw = {}, {}
+    if c["kv"] == "i8":
+        a_s, a_o = datagen.antiquant_case(seed, Hkv, D, seed % 4 != 0)
+        kw = dict(antiq_scale=H.dev(a_s), antiq_offset=None if a_o is None else H.dev(a_o))
+        okw = dict(antiquant_scale=a_s.astype(np.float32),
+                   antiquant_offset=None if a_o is None else a_o.astype(np.float32))
+    scale = D ** -0.5
+    P = 256
+    want, wpos, wlen, wmax = ref.sparse_paged_fusion_attention(
+        q, kc, vc, table, l1, ids, seq, Hq, Hkv, scale, bs, k, P, sink_recent=c["sink_recent"],
+        max_pages_cap=c["cap"], **okw)
+    kd, vd = (H.dev(kc), H.dev(vc)) if c["kv"] == "i8" else (H.dev(kc, tdt), H.dev(vc, tdt))
+    qd, l1d, td, idsd, seqd = H.dev(q, tdt), H.dev(l1, tdt), H.dev(table), H.dev(ids), H.dev(seq)
+    out, pos, plen, pmax = H.call_fusion(qd, kd, vd, td, l1d, idsd, seqd, Hq, Hkv, scale, bs, k, P=P,
+                                         out_dtype=torch.float32, sink_recent=c["sink_recent"],
+                                         max_pages_cap=c["cap"], **kw)
+    info = f"{c}"
+    assert np.array_equal(pos.cpu().numpy(), wpos), info
+    assert np.array_equal(plen.cpu().numpy(), wlen), info
+    assert np.array_equal(pmax.cpu().numpy(), wmax), info
+    err = float(parity.rel_err(H.f32(out)[:B], want).max())
+    assert err <= TOL, f"max rel err {err:.3e} {info}"
+    # the separate ops on the same inputs (page size of cent_select is a knob; the reference compiles in 128)
+    spos, slen, smax = custom_ops.cent_select(qd, l1d, idsd, td, seqd, k=k, sink_recent=c["sink_recent"],
+                                              max_pages_cap=c["cap"], max_page_num=P, page_size=bs)
+    assert torch.equal(spos, pos) and torch.equal(slen, plen) and torch.equal(smax, pmax), info
+    idx = custom_ops.compute_cent(qd, l1d, k=k).cpu().numpy()
+    assert np.array_equal(idx[:B], ref.compute_cent(q, l1, k)[:B]), info
+
+
+SENT = 0x7FFFFFFF
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SPFA_FUZZ_SEEDS", "120")) // 2))
+def test_random_lists(seed):
+    """sparse_paged_attention on given lists: both KV layouts, lists per q head or per kv head, sentinel-terminated
+    rows of any length (empty ones included), all forms of actual_seq_lengths, optional bias / mask / int8 output."""
+    import gpu_helpers as H
+    rng = datagen.rng_for(7000 + seed)
+    kv = ["f16", "bf16", "i8"][seed % 3]
+    D = int(rng.choice([32, 64, 128, 256, 512])) if kv != "i8" else int(rng.choice([64, 128, 256, 512]))
+    G = int(rng.choice([1, 2, 4, 5, 16]))
+    Hkv = int(rng.choice([1, 2, 4]))
+    Hq = G * Hkv
+    bs = int(rng.choice([32, 64, 128])) if kv == "i8" else int(rng.choice([16, 48, 128, 512]))
+    layout = "BSH" if seed % 2 == 0 else "BNSD"
+    rows = Hq if seed % 4 < 2 else Hkv
+    B, n_blocks, max_page = int(rng.integers(1, 5)), 24, int(rng.integers(2, 20))
+    P = int(rng.integers(1, max_page + 3))
+    tdt = torch.bfloat16 if kv == "bf16" else torch.float16
+    q = datagen.ref_rand_f16(rng, (B, Hq, D))
+    k, v = datagen.kv_case(seed, n_blocks, bs, Hkv, D, layout, dist="randn", dtype="i8" if kv == "i8" else "f16")
+    if kv == "bf16":
+        q, k, v = (ref.round_to_bf16(x.astype(np.float32)) for x in (q, k, v))
+    table = rng.integers(0, n_blocks, size=(B + 1, max_page)).astype(np.int32)
+    pos = np.full((B, rows, P), SENT, np.int32)
+    for b in range(B):
+        for r in range(rows):
+            n = int(rng.integers(0, min(P, max_page) + 1))
+            pos[b, r, :n] = np.sort(rng.choice(max_page, size=n, replace=False))
+    mode = seed % 5
+    act_host, act_arg = None, torch.empty(0, dtype=torch.int64)
+    if mode == 1:
+        act_host, act_arg = [3 * bs - 1] * B, [3 * bs - 1]
+    elif mode >= 2:
+        act_host = [int(x) for x in rng.integers(1, P * bs + 1, size=B)]
+        act_arg = torch.tensor(act_host, dtype=torch.int64)
+        if mode == 3:
+            act_arg = act_arg.to(H.DEV)
+    kw, okw = {}, {}
+    if kv == "i8":
+        a_s, a_o = datagen.antiquant_case(seed, Hkv, D, seed % 2 == 0)
+        kw = dict(antiq_scale=H.dev(a_s), antiq_offset=None if a_o is None else H.dev(a_o))
+        okw = dict(antiquant_scale=a_s.astype(np.float32), antiquant_offset=None if a_o is None else a_o.astype(np.float32))
+    if seed % 6 == 1:      # score bias and mask over the columns of the gathered sequence
+        S = max_page * bs
+        pse = (rng.standard_normal((1 if seed % 12 == 1 else B, Hq, 1, S)) * 2).astype(np.float16)
+        if kv == "bf16":
+            pse = ref.round_to_bf16(pse.astype(np.float32))
+        mask = rng.random((B, S)) < 0.25
+        kw.update(pse=H.dev(pse, tdt), mask=H.dev(mask))
+        okw.update(pse_shift=pse, atten_mask=mask)
+    scale = D ** -0.5
+    want = ref.sparse_paged_attention(q, k, v, table, pos, act_host, Hq, Hkv, scale, bs, layout, **okw)
+    kd, vd = (H.dev(k), H.dev(v)) if kv == "i8" else (H.dev(k, tdt), H.dev(v, tdt))
+    args = (H.dev(q, tdt), kd, vd, H.dev(table), H.dev(pos), act_arg, Hq, Hkv, scale, bs)
+    out = H.f32(H.call_attention(*args, out_dtype=torch.float32, **kw))
+    info = dict(kv=kv, D=D, G=G, Hkv=Hkv, bs=bs, layout=layout, rows=rows, B=B, P=P, max_page=max_page, mode=mode)
+    err = float(parity.rel_err(out, want).max())
+    assert err <= TOL, f"max rel err {err:.3e} {info}"
+    empty = (pos[:, :, 0] == SENT)
+    for b in range(B):
+        for h in range(Hq):
+            if empty[b, h if rows == Hq else h // G]:
+                assert (out[b, h] == 0).all(), info
+    if seed % 6 == 2:      # int8 output of the same launch
+        sc = (rng.random(Hq * D) * 400 + 100).astype(np.float32)
+        out8 = H.call_attention(*args, quant_scale2=H.dev(sc.reshape(1, Hq, 1, D)), **kw)
+        assert np.array_equal(out8.cpu().numpy().astype(np.float32), ref.post_quant(out, sc)), info
