@@ -153,3 +153,50 @@ def test_random_lists(seed):
         sc = (rng.random(Hq * D) * 400 + 100).astype(np.float32)
         out8 = H.call_attention(*args, quant_scale2=H.dev(sc.reshape(1, Hq, 1, D)), **kw)
         assert np.array_equal(out8.cpu().numpy().astype(np.float32), ref.post_quant(out, sc)), info
+
+
+@pytest.mark.parametrize("seed", range(max(4, int(os.environ.get("SPFA_FUZZ_SEEDS", "120")) // 6)))
+def test_medium_shape(seed):
+    """Launches with more items than resident workgroups, long tables (several 256-page scan steps), rows that overflow
+    their P slots, groups up to 64 heads, big cluster counts: checked against the multi-threaded C oracle."""
+    import gpu_helpers as H
+    from oracle import cport
+    rng = datagen.rng_for(5000 + seed)
+    kv = "i8" if seed % 3 == 2 else "f16"
+    G = int(rng.choice([1, 4, 8, 32, 64]))
+    Hkv = int(rng.choice([1, 2, 8])) if G > 1 else int(rng.choice([8, 32]))
+    while G * Hkv > 64:
+        Hkv //= 2
+    Hq = G * Hkv
+    D = int(rng.choice([64, 128]))
+    bs = int(rng.choice([32, 128])) if kv == "i8" else int(rng.choice([16, 128]))
+    C = int(rng.choice([512, 2048, 4096]))
+    k = int(rng.choice([8, 32, 64, 200]))
+    B = int(rng.integers(8, 71))
+    max_page = int(rng.integers(40, 600))
+    P = int(rng.choice([16, 256, 640]))
+    seq_lens = [int(x) for x in rng.integers(1, max_page * bs + 1, size=B)]
+    seq_lens[0] = max_page * bs
+    kv_page_len = 600
+    q, l1 = datagen.cent_case(seed, B, Hq, Hkv, D, C, grid=True)
+    ids, table, seq = datagen.page_case(seed, Hkv, C, kv_page_len, B, max_page, seq_lens)
+    ids[:] = ids % int(rng.choice([C, 97, 300]))      # fewer distinct ids: longer lists
+    kc, vc = datagen.kv_case(seed, kv_page_len, bs, Hkv, D, "BSH", dist="randn", dtype=kv)
+    a_s = a_o = None
+    kw = {}
+    if kv == "i8":
+        a_s, a_o = datagen.antiquant_case(seed, Hkv, D, True)
+        kw = dict(antiq_scale=H.dev(a_s), antiq_offset=H.dev(a_o))
+    scale = D ** -0.5
+    sink, cap = bool(seed % 4 == 1), bool(seed % 5 == 2)
+    want, wpos, wlen, wmax = cport.fusion(q, kc, vc, table, l1, ids, seq, Hq, Hkv, scale, bs, k, P, sink, cap,
+                                          kv_dt=kv, antiq_scale=a_s, antiq_offset=a_o)
+    out, pos, plen, pmax = H.call_fusion(H.dev(q), H.dev(kc), H.dev(vc), H.dev(table), H.dev(l1), H.dev(ids),
+                                         H.dev(seq), Hq, Hkv, scale, bs, k, P=P, out_dtype=torch.float32,
+                                         sink_recent=sink, max_pages_cap=cap, **kw)
+    info = dict(kv=kv, G=G, Hkv=Hkv, D=D, bs=bs, C=C, k=k, B=B, max_page=max_page, P=P, sink=sink, cap=cap)
+    assert np.array_equal(pos.cpu().numpy(), wpos), info
+    assert np.array_equal(plen.cpu().numpy(), wlen), info
+    assert np.array_equal(pmax.cpu().numpy(), wmax), info
+    err = float(parity.rel_err(H.f32(out), want).max())
+    assert err <= TOL, f"max rel err {err:.3e} {info}"
