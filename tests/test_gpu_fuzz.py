@@ -200,3 +200,38 @@ def test_medium_shape(seed):
     assert np.array_equal(pmax.cpu().numpy(), wmax), info
     err = float(parity.rel_err(H.f32(out), want).max())
     assert err <= TOL, f"max rel err {err:.3e} {info}"
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SPFA_FUZZ_SEEDS", "120")) // 3))
+def test_random_select_position(seed):
+    """The standalone SelectPosition op: indices with repeats, tables longer than one scan step, rows that overflow the
+    slot count, batch taken from seq_len (shorter than the index batch)."""
+    import custom_ops
+    import gpu_helpers as H
+    rng = datagen.rng_for(3000 + seed)
+    G = int(rng.choice([1, 2, 4, 8]))
+    Hkv = int(rng.choice([1, 2, 3, 8]))
+    Hq = G * Hkv
+    C = int(rng.choice([4, 16, 100, 1000]))
+    k = int(rng.choice([1, 3, 8, 64]))
+    bs = int(rng.choice([16, 128]))
+    B = int(rng.integers(1, 7))
+    max_page = int(rng.integers(1, 700))
+    kv_page_len = int(rng.integers(1, 900))
+    P = int(rng.choice([8, 256, 300]))
+    seq_lens = [int(x) for x in rng.integers(1, max_page * bs + 1, size=B)]
+    ids = rng.integers(0, C, size=(Hkv, kv_page_len)).astype(np.int32)
+    # values outside [0, kv_page_len) are clamped by the op (tests/utils.py:62)
+    table = rng.integers(-3, kv_page_len + 3, size=(B + 2, max_page)).astype(np.int32)
+    seq = np.array(seq_lens, np.int32)
+    idx = rng.integers(0, C, size=(B + 1, Hq, k)).astype(np.int32)
+    wpos, wlen, wgather = ref.select_position(ids, table, seq, idx, bs, P)
+    pos, length, gather = custom_ops.select_position(H.dev(ids), H.dev(table), H.dev(seq), H.dev(idx), max_page_num=P,
+                                                     page_size=bs)
+    info = dict(G=G, Hkv=Hkv, C=C, k=k, bs=bs, B=B, max_page=max_page, kv_page_len=kv_page_len, P=P)
+    pos, length, gather = pos.cpu().numpy(), length.cpu().numpy(), gather.cpu().numpy()
+    assert pos.shape[0] == idx.shape[0] and length.shape == (idx.shape[0], Hq, 8), info
+    assert np.array_equal(pos[:B], wpos), info
+    assert (length[:B] == wlen[:, :, None]).all(), info
+    w = wgather.shape[2]
+    assert np.array_equal(gather[:B, :, :w], wgather), info
