@@ -21,6 +21,26 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-3
 
 
+class _Knobs:
+    """Launch-planning knobs for one test: tail sharing forced on / off, page-list split off (all restored)."""
+
+    def __init__(self, seed):
+        self.tail = {3: 2, 6: 0}.get(seed % 8, 1)
+        self.split = 1 if seed % 8 == 5 else (3 if seed % 8 == 1 else 16)
+
+    def __enter__(self):
+        from custom_ops import _abi
+        _abi.check(_abi.spfaSetTailSharing(self.tail), "spfaSetTailSharing")
+        _abi.check(_abi.spfaSetMaxSplit(self.split), "spfaSetMaxSplit")
+        return self
+
+    def __exit__(self, *exc):
+        from custom_ops import _abi
+        _abi.spfaSetTailSharing(1)
+        _abi.spfaSetMaxSplit(16)
+        return False
+
+
 def _draw(seed):
     rng = datagen.rng_for(9000 + seed)
     kv = ["f16", "bf16", "i8"][seed % 3]
@@ -67,10 +87,11 @@ def test_random_shape(seed):
         max_pages_cap=c["cap"], **okw)
     kd, vd = (H.dev(kc), H.dev(vc)) if c["kv"] == "i8" else (H.dev(kc, tdt), H.dev(vc, tdt))
     qd, l1d, td, idsd, seqd = H.dev(q, tdt), H.dev(l1, tdt), H.dev(table), H.dev(ids), H.dev(seq)
-    out, pos, plen, pmax = H.call_fusion(qd, kd, vd, td, l1d, idsd, seqd, Hq, Hkv, scale, bs, k, P=P,
-                                         out_dtype=torch.float32, sink_recent=c["sink_recent"],
-                                         max_pages_cap=c["cap"], **kw)
-    info = f"{c}"
+    with _Knobs(seed) as knobs:
+        out, pos, plen, pmax = H.call_fusion(qd, kd, vd, td, l1d, idsd, seqd, Hq, Hkv, scale, bs, k, P=P,
+                                             out_dtype=torch.float32, sink_recent=c["sink_recent"],
+                                             max_pages_cap=c["cap"], **kw)
+    info = f"{c} tail_sharing={knobs.tail} max_split={knobs.split}"
     assert np.array_equal(pos.cpu().numpy(), wpos), info
     assert np.array_equal(plen.cpu().numpy(), wlen), info
     assert np.array_equal(pmax.cpu().numpy(), wmax), info
@@ -140,7 +161,8 @@ def test_random_lists(seed):
     want = ref.sparse_paged_attention(q, k, v, table, pos, act_host, Hq, Hkv, scale, bs, layout, **okw)
     kd, vd = (H.dev(k), H.dev(v)) if kv == "i8" else (H.dev(k, tdt), H.dev(v, tdt))
     args = (H.dev(q, tdt), kd, vd, H.dev(table), H.dev(pos), act_arg, Hq, Hkv, scale, bs)
-    out = H.f32(H.call_attention(*args, out_dtype=torch.float32, **kw))
+    with _Knobs(seed):
+        out = H.f32(H.call_attention(*args, out_dtype=torch.float32, **kw))
     info = dict(kv=kv, D=D, G=G, Hkv=Hkv, bs=bs, layout=layout, rows=rows, B=B, P=P, max_page=max_page, mode=mode)
     err = float(parity.rel_err(out, want).max())
     assert err <= TOL, f"max rel err {err:.3e} {info}"
@@ -191,9 +213,10 @@ def test_medium_shape(seed):
     sink, cap = bool(seed % 4 == 1), bool(seed % 5 == 2)
     want, wpos, wlen, wmax = cport.fusion(q, kc, vc, table, l1, ids, seq, Hq, Hkv, scale, bs, k, P, sink, cap,
                                           kv_dt=kv, antiq_scale=a_s, antiq_offset=a_o)
-    out, pos, plen, pmax = H.call_fusion(H.dev(q), H.dev(kc), H.dev(vc), H.dev(table), H.dev(l1), H.dev(ids),
-                                         H.dev(seq), Hq, Hkv, scale, bs, k, P=P, out_dtype=torch.float32,
-                                         sink_recent=sink, max_pages_cap=cap, **kw)
+    with _Knobs(seed):
+        out, pos, plen, pmax = H.call_fusion(H.dev(q), H.dev(kc), H.dev(vc), H.dev(table), H.dev(l1), H.dev(ids),
+                                             H.dev(seq), Hq, Hkv, scale, bs, k, P=P, out_dtype=torch.float32,
+                                             sink_recent=sink, max_pages_cap=cap, **kw)
     info = dict(kv=kv, G=G, Hkv=Hkv, D=D, bs=bs, C=C, k=k, B=B, max_page=max_page, P=P, sink=sink, cap=cap)
     assert np.array_equal(pos.cpu().numpy(), wpos), info
     assert np.array_equal(plen.cpu().numpy(), wlen), info
