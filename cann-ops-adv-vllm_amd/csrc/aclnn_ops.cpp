@@ -444,7 +444,7 @@ aclnnStatus aclnnCentSelect(void*, uint64_t, aclOpExecutor* executor, aclrtStrea
     const spfa::CentParams& p = executor->cent;
     hipError_t err = hipSuccess;
     if (p.B > 0)   // the per-batch maximum is accumulated with atomicMax
-        err = hipMemsetAsync(p.max_page_position_length, 0, (size_t)p.B * spfa::kLenPad * 8, (hipStream_t)stream);
+        err = spfa::launch_zero(p.max_page_position_length, (size_t)p.B * spfa::kLenPad * 8, nullptr, 0, (hipStream_t)stream);
     if (err == hipSuccess) err = spfa::launch_cent_select(p, (hipStream_t)stream);
     return finish(executor, err, "cent_select launch");
 }
@@ -738,7 +738,9 @@ static void plan_workspace(aclOpExecutor* e) {
 }
 
 // Bind the planned workspace layout to the caller's buffer and enqueue the zeroing of its counters.
-static hipError_t bind_workspace(const aclOpExecutor* e, spfa::AttnParams& p, void* workspace, hipStream_t stream) {
+static hipError_t bind_workspace(const aclOpExecutor* e, spfa::AttnParams& p, void* workspace, hipStream_t stream,
+                                 void* also_zero = nullptr, size_t also_bytes = 0) {
+    if (((uintptr_t)workspace & 15) != 0) return hipErrorInvalidValue;   // 64-bit atomics and 16-byte boards live in it
     p.counters = (unsigned*)workspace;
     p.split_done = (unsigned*)((char*)workspace + kCounterBytes);
     p.split_partials = (float*)((char*)workspace + e->ws_parts_off);
@@ -746,7 +748,8 @@ static hipError_t bind_workspace(const aclOpExecutor* e, spfa::AttnParams& p, vo
     p.tail_data = (char*)workspace + e->ws_tail_off;
     p.pg_done = (unsigned*)((char*)workspace + e->ws_pgdone_off);
     p.pg_keys = (uint32_t*)((char*)workspace + e->ws_pgkeys_off);
-    return hipMemsetAsync(workspace, 0, e->ws_zero_bytes, stream);
+    // (+ the per-batch maxima of the fused op, accumulated with atomicMax) in one small kernel
+    return spfa::launch_zero(workspace, e->ws_zero_bytes, also_zero, also_bytes, stream);
 }
 
 #define REJECT_PRESENT(t, name) \
@@ -930,9 +933,8 @@ aclnnStatus aclnnSparsePagedFusionAttention(void* workspace, uint64_t workspaceS
         if (!executor->repeatable) delete executor;
         return fail(ACLNN_ERR_PARAM_INVALID, "workspace of %llu bytes required", need);
     }
-    hipError_t err = bind_workspace(executor, p, workspace, (hipStream_t)stream);
-    if (err == hipSuccess && p.max_page_position_length && p.B > 0)   // accumulated with atomicMax
-        err = hipMemsetAsync(p.max_page_position_length, 0, (size_t)p.B * spfa::kLenPad * 8, (hipStream_t)stream);
+    hipError_t err = bind_workspace(executor, p, workspace, (hipStream_t)stream, p.max_page_position_length,
+                                    p.max_page_position_length ? (size_t)p.B * spfa::kLenPad * 8 : 0);
     if (err == hipSuccess) err = spfa::launch_attention(p, (hipStream_t)stream);
     return finish(executor, err, "sparse_paged_fusion_attention launch");
 }

@@ -1903,6 +1903,23 @@ hipError_t launch_attn_mfma(const AttnParams& p, int lpt, hipStream_t s, long lo
 
 }  // namespace
 
+// Zero two 8-byte aligned ranges (workspace counters, the per-batch maxima that the kernels accumulate with atomicMax)
+// in one small launch: unlike a memset node this behaves the same when the stream is being captured into a graph.
+__global__ void zero_kernel(unsigned long long* a, size_t na, unsigned long long* b, size_t nb) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, step = (size_t)gridDim.x * blockDim.x;
+    for (size_t j = i; j < na; j += step) a[j] = 0ull;
+    for (size_t j = i; j < nb; j += step) b[j] = 0ull;
+}
+
+hipError_t launch_zero(void* a, size_t a_bytes, void* b, size_t b_bytes, hipStream_t s) {
+    const size_t na = a ? a_bytes / 8 : 0, nb = b ? b_bytes / 8 : 0;
+    if (na + nb == 0) return hipSuccess;
+    const size_t most = na > nb ? na : nb;
+    const unsigned blocks = (unsigned)((most + 255) / 256 < 64 ? (most + 255) / 256 : 64);
+    hipLaunchKernelGGL(zero_kernel, dim3(blocks), dim3(256), 0, s, (unsigned long long*)a, na, (unsigned long long*)b, nb);
+    return hipGetLastError();
+}
+
 int device_cu_count() {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;

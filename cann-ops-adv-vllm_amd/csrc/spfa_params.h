@@ -125,6 +125,8 @@ hipError_t launch_cent_select(const CentParams& p, hipStream_t s);
 hipError_t launch_select_position(const SelectParams& p, hipStream_t s);
 // cap_out != nullptr: launch nothing, report how many workgroups of the kernel that would run can be resident.
 hipError_t launch_attention(const AttnParams& p, hipStream_t s, long long* cap_out = nullptr);
+// Enqueue the zeroing of up to two 8-byte aligned ranges (either may be null / empty) as one small kernel.
+hipError_t launch_zero(void* a, size_t a_bytes, void* b, size_t b_bytes, hipStream_t s);
 // Compute units of the current device (0 when no device can be queried).
 int device_cu_count();
 // Number of q heads of a group one pass over the K/V pages serves, and whether that pass runs on the MFMA streamer
