@@ -768,7 +768,8 @@ aclnnStatus aclnnSparsePagedAttentionGetWorkspaceSize(
     REJECT_PRESENT(dequantScale1, "dequantScale1");   // int8 queries are not part of this path
     REJECT_PRESENT(quantScale1, "quantScale1");
     REJECT_PRESENT(dequantScale2, "dequantScale2");
-    REJECT_PRESENT(kvPaddingSize, "kvPaddingSize");
+    (void)kvPaddingSize;   // left padding only exists for contiguous KV: with a block table the reference drops it too
+                           // (…_tiling_check.cc:590-594)
     aclOpExecutor* e = new aclOpExecutor();
     e->op = kOpAttention;
     spfa::AttnParams& p = e->attn;
@@ -865,7 +866,8 @@ aclnnStatus aclnnSparsePagedFusionAttentionGetWorkspaceSize(
     REJECT_PRESENT(dequantScale1, "dequantScale1");   // int8 queries are not part of this path
     REJECT_PRESENT(quantScale1, "quantScale1");
     REJECT_PRESENT(dequantScale2, "dequantScale2");
-    REJECT_PRESENT(kvPaddingSize, "kvPaddingSize");
+    (void)kvPaddingSize;   // left padding only exists for contiguous KV: with a block table the reference drops it too
+                           // (…_tiling_check.cc:590-594)
     int Hq = 0, Hkv = 0, D = 0, C = 0;
     CHECK(check_qcent(query, l1_cent, &Hq, &Hkv, &D, &C));
     int B = 0, kv_page_len = 0, max_page = 0;

@@ -139,7 +139,8 @@ def sparse_paged_attention(query: torch.Tensor, key: torch.Tensor, value: torch.
     (bool / int8 / uint8, non zero = masked) replaces them by -1e12; both run over the columns of the gathered
     sequence, list slot * block_size + token.  quant_scale2 / quant_offset2 (float32 or bfloat16; one value or
     num_heads * D) turn the output into int8.  antiquant_scale / antiquant_offset may be [2, Hkv, D] (per channel)
-    or [2] (per tensor).  dequant_scale1, quant_scale1, dequant_scale2 and kv_padding_size must be empty."""
+    or [2] (per tensor).  dequant_scale1, quant_scale1 and dequant_scale2 must be empty; kv_padding_size is ignored (paged KV
+    has no left padding, sparse_paged_fusion_attention_tiling_check.cc:590-594)."""
     _abi.require_gpu(query, key, value, blocktable, blockposition)
     dev = query.device
     out = torch.empty(query.shape, dtype=out_dtype or _default_out_dtype(query, quant_scale2), device=dev)

@@ -25,7 +25,9 @@
  *   quantScale2 / quantOffset2  float32 (or bfloat16 with a bfloat16 query), 1 value or Hq*D values
  *              ([1,Hq,1,D] and the other spellings of …_tiling_check.cc:412-464): attentionOut is int8,
  *              round(out * scale2 + offset2) through float16, ties away from zero, saturating (kernel :4016-4111).
- * dequantScale1, quantScale1, dequantScale2 (int8 queries) and kvPaddingSize must be NULL: not on this path.
+ * dequantScale1, quantScale1, dequantScale2 (int8 queries) must be NULL: not on this path.  kvPaddingSize is accepted and
+ * ignored: left padding only exists for contiguous KV, with a block table the reference drops it as well
+ * (sparse_paged_fusion_attention_tiling_check.cc:590-594).
  */
 #ifndef SPFA_ACLNN_SPARSE_PAGED_ATTENTION_H_
 #define SPFA_ACLNN_SPARSE_PAGED_ATTENTION_H_

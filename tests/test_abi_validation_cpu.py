@@ -132,6 +132,24 @@ def test_score_bias_mask_and_output_quantisation_operands(lib):
     assert st == PARAM_INVALID and "antiquantScale" in msg
 
 
+def test_kv_padding_is_ignored_with_a_block_table(lib):
+    """…_tiling_check.cc:590-594: left padding is dropped whenever page attention is on."""
+    q = tensor(lib, (3, 8, 128), F16)
+    k, v = tlist(lib, tensor(lib, (40, 128, 2, 128), F16)), tlist(lib, tensor(lib, (40, 128, 2, 128), F16))
+    ws, ex = c_uint64(0), c_void_p()
+    st = lib.aclnnSparsePagedAttentionGetWorkspaceSize(
+        q, k, v, None, None, None, None, None, None, None, None, None, None, tensor(lib, (3, 24), I32),
+        tensor(lib, (1,), I64), tensor(lib, (3, 2, 12), I32), 8, 0.088, b"BNSD", 2, 128, 1, tensor(lib, (3, 8, 128), F16),
+        ctypes.byref(ws), ctypes.byref(ex))
+    assert st == 0, lib.aclGetRecentErrMsg()
+    lib.aclDestroyAclOpExecutor(ex)
+    st = lib.aclnnSparsePagedAttentionGetWorkspaceSize(
+        q, k, v, None, None, None, tensor(lib, (1,), F32), None, None, None, None, None, None, tensor(lib, (3, 24), I32),
+        None, tensor(lib, (3, 2, 12), I32), 8, 0.088, b"BNSD", 2, 128, 1, tensor(lib, (3, 8, 128), F16),
+        ctypes.byref(ws), ctypes.byref(ex))
+    assert st == PARAM_INVALID and b"dequantScale1" in lib.aclGetRecentErrMsg()
+
+
 def test_unsupported_operands_and_null_pointers(lib):
     st, _, msg = attention(lib, antiq=tensor(lib, (2, 2, 128), F16))
     assert st == PARAM_INVALID and "antiquant" in msg
