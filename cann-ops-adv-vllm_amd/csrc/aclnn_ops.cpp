@@ -466,6 +466,8 @@ static aclnnStatus plan_attention(spfa::AttnParams& p, const aclTensor* query, c
     REQUIRE(Hq % Hkv == 0, "numHeads %d not divisible by numKeyValueHeads %d", Hq, Hkv);
     REQUIRE(Hq / Hkv <= 64, "group size %d exceeds 64 (…_tiling_check.cc:171)", Hq / Hkv);
     const std::string layout = inputLayout ? inputLayout : "BNSD";
+    REQUIRE(layout == "BSH" || layout == "BNSD" || layout == "BSND",
+            "Only support input_layout(BSH, BNSD, BSND), actually is %s (…_tiling.cc:226)", layout.c_str());
     // decode only: S = 1, so every accepted layout is [B, Hq, D] in memory
     int B = 0, D = 0;
     const auto& qd = query->dims;
@@ -503,6 +505,8 @@ static aclnnStatus plan_attention(spfa::AttnParams& p, const aclTensor* query, c
             (long long)blockSize, quant ? 32 : 16);
     const int bs = (int)blockSize;
     const auto& kd = kc->dims;
+    REQUIRE(kd.size() != 4 || layout == "BNSD",
+            "with a 4-dim paged KV cache the query layout must be BNSD (…_tiling.cc:341-343)");
     bool bsh;
     if (kd.size() == 3) {
         REQUIRE(kd[1] == bs && kd[2] == (int64_t)Hkv * D, "KV cache must be [blocks, blockSize, Hkv*D]");
