@@ -486,6 +486,7 @@ static aclnnStatus plan_attention(spfa::AttnParams& p, const aclTensor* query, c
     } else {
         return fail(ACLNN_ERR_PARAM_INVALID, "query must have 3 or 4 dims");
     }
+    REQUIRE(B <= 65536, "batch size %d cannot be greater than 65536 (…_tiling_check.cc:215)", B);
     REQUIRE(D > 0 && D <= 512, "head dim %d out of range (…_tiling_check.cc:219)", D);
     REQUIRE(Hkv <= 256, "numKeyValueHeads %d exceeds 256 (…_tiling_check.cc:222)", Hkv);
 

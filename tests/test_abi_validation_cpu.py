@@ -86,6 +86,7 @@ def test_attention_plans_without_a_device(lib):
     (dict(kv_shape=(40, 128, 2, 64)), "KV cache must be"),
     (dict(out_dtype=I32), "attentionOut dtype"),
     (dict(D=80, kv_shape=(40, 128, 2, 80)), "head dim"),
+    (dict(B=65537), "batch size"),
     (dict(layout=b"SBH"), "Only support input_layout"),
     (dict(layout=b"BSND"), "query layout must be BNSD"),          # 4-dim cache
     (dict(D=512, kv_dtype=I8, kv_shape=(40, 128, 2, 512)), "int8 KV cache needs"),   # the shape itself is accepted
