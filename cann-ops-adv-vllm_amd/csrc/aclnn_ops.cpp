@@ -714,7 +714,7 @@ static void plan_workspace(aclOpExecutor* e) {
     const uint64_t cent_bytes_per_class = (uint64_t)((p.Hkv + 7) / 8) * p.C * p.D * 2;
     p.class_step = (p.mode == 0 || 2 * cent_bytes_per_class <= (2u << 20)) ? 1 : 0;
     // Sharing of every workgroup's last item (launches without a split): one board + data area per resident
-    // workgroup (at most two per CU): header, page list, q rows of the VALU streamer, 17 states.
+    // workgroup (at most two per CU): header, page list, q rows of the VALU streamer, 1 + tail_chunks states.
     // The protocol costs about 10 us per workgroup (claims, one more state to merge); it pays when a workgroup has
     // several items to be out of step by, or long ones.
     // Group passes (MFMA streamer) run one workgroup per CU with a few long, unequal items each (the union of a
