@@ -722,7 +722,7 @@ static void plan_workspace(aclOpExecutor* e) {
     const bool mfma = spfa::attention_uses_mfma(p.rows_per_pass, p.kv_dtype, p.D);
     const bool worth = items >= 6ll * n_cu || (items > n_cu && (p.max_entries >= 512 || mfma));
     p.tail_on = (g_tail_sharing && p.n_split == 1 && n_cu > 0 && (worth || g_tail_sharing == 2)) ? 1 : 0;
-    const uint64_t n_boards = p.tail_on ? 2ull * n_cu : 0;
+    const uint64_t n_boards = p.tail_on ? (uint64_t)(cap > 0 ? cap : 2ll * n_cu) : 0;   // one per resident workgroup
     const uint64_t state_bytes = (uint64_t)p.rows_per_pass * (p.D + 2) * 4;
     p.tail_chunks = p.rows_per_pass <= 4 ? 32 : 16;   // one state per chunk + the owner's: keep the wide ones fewer
     p.tail_stride = (long long)up256(32 + (uint64_t)p.max_entries * 8 + (mfma ? 0 : (uint64_t)p.rows_per_pass * p.D * 4) + 16 +
