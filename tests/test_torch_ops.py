@@ -77,3 +77,31 @@ def test_dispatcher_ops_equal_python_ops():
     b = fused(custom_ops.sparse_paged_fusion_attention, lambda x: x)
     assert all(torch.equal(x, y) for x, y in zip(a, b))
     assert torch.equal(a[1], pos) and torch.equal(a[2], plen) and torch.equal(a[3], pmax)
+
+
+@pytest.mark.gpu
+def test_dispatcher_passes_the_optional_operands():
+    """pse_shift / attention_mask / quant_scale2 travel through the registered schema like any other tensor."""
+    dev = "cuda:0"
+    B, Hq, Hkv, D, bs, pages = 2, 4, 4, 128, 128, 6
+    rng = datagen.rng_for(3)
+    q = torch.from_numpy(datagen.ref_rand_f16(rng, (B, Hq, D))).to(dev)
+    k_np, v_np = datagen.kv_case(3, B * pages, bs, Hkv, D, "BSH", dist="randn")
+    key, val = torch.from_numpy(k_np).to(dev), torch.from_numpy(v_np).to(dev)
+    table = torch.arange(B * pages, dtype=torch.int32, device=dev).reshape(B, pages)
+    pos = torch.arange(pages, dtype=torch.int32, device=dev).repeat(B, Hkv, 1).contiguous()
+    e = torch.empty(0, dtype=torch.float16, device=dev)
+    ei = torch.empty(0, dtype=torch.int64, device=dev)
+    S = pages * bs
+    pse = torch.from_numpy((rng.standard_normal((B, Hq, 1, S)) * 2).astype(np.float16)).to(dev)
+    mask = torch.from_numpy(rng.random((B, S)) < 0.3).to(dev)
+    sc = torch.full((1,), 300.0, dtype=torch.float32, device=dev)
+    act = torch.tensor([S] * B)
+    args = lambda kv: (q, kv(key), kv(val), pse, mask, act, e, e, e, sc, e, e, e, table, ei, pos, Hq, D ** -0.5, "BNSD",
+                       Hkv, bs, 1)
+    o1 = torch.ops.myops.sparse_paged_attention(*args(lambda x: [x]))
+    o2 = custom_ops.sparse_paged_attention(*args(lambda x: x))
+    assert o1.dtype == torch.int8 and torch.equal(o1, o2)
+    plain = custom_ops.sparse_paged_attention(q, key, val, e, e, act, e, e, e, sc, e, e, e, table, ei, pos, Hq, D ** -0.5,
+                                              "BNSD", Hkv, bs, 1)
+    assert not torch.equal(o1, plain)          # bias and mask took effect
