@@ -9,7 +9,11 @@ synthetic inputs in the reference's distributions, a 32 GiB disjoint KV pool (>>
 Infinity Cache) and "budgeted" block_ids so every head selects pageLen/8 = 32 pages (the reference's
 design point, fused_ifa_v5_case.py:33-34).
 
-    python bench.py [--gpus N --steps K --warmup W]          # N>1: launched under torch.distributed.run
+    python bench.py [--gpus N --steps K --warmup W] [--workload c3|c4|c5]
+
+With --gpus N > 1 and no WORLD_SIZE in the environment the script starts N ranks itself (one process per GPU
+under torch.distributed.run, RCCL backend) before it touches the GPU, and exits with their status; started
+under torch.distributed.run it is one of the ranks.  Weak scaling: every rank holds `--batch` sequences.
 
 Prints ONE JSON line (rank 0).  `value` = decode tokens/s of the whole job with inputs resident in HBM.
 `roofline` prices the fused kernel against the HBM roofline with ALGORITHMIC bytes of the KV gather
@@ -34,7 +38,15 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (≈6.3 TB/s is what a streaming copy achieves)
 
 
-def parse():
+# Shape presets (BASELINE.json configs[2..4]); 64 sequences per GPU in all of them.
+WORKLOADS = {
+    "c3": dict(batch=64, heads=32, kv_heads=32, head_dim=128, seqlen=32 * 1024, clusters=2048, topk=32, kv="f16"),
+    "c4": dict(batch=64, heads=32, kv_heads=32, head_dim=128, seqlen=64 * 1024, clusters=2048, topk=32, kv="int8"),
+    "c5": dict(batch=64, heads=32, kv_heads=8, head_dim=128, seqlen=128 * 1024, clusters=2048, topk=64, kv="f16"),
+}
+
+
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -57,7 +69,14 @@ def parse():
     ap.add_argument("--no-tail-sharing", action="store_true", help="diagnostic: spfaSetTailSharing(0)")
     ap.add_argument("--force-tail-sharing", action="store_true", help="diagnostic: spfaSetTailSharing(2)")
     ap.add_argument("--no-shared-scoring", action="store_true", help="diagnostic: spfaSetSharedScoring(0)")
-    return ap.parse_args()
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default=None,
+                    help="preset shape: c3 = BASELINE configs[2] (the default shape), c4 = configs[3] (int8 KV, S=64k), "
+                         "c5 = configs[4] (GQA 32/8, S=128k, k=64; 64 sequences per GPU, 512 in all on 8 GPUs)")
+    a = ap.parse_args(argv)
+    if a.workload:
+        for key, val in WORKLOADS[a.workload].items():
+            setattr(a, key, val)
+    return a
 
 
 def build_workload(a, device, B, seed, custom_ops):
@@ -178,6 +197,8 @@ def cpu_baseline(a, wl, custom_ops, plan_args):
     denom = np.maximum(np.abs(out), 1e-2 * np.abs(out).max())
     parity = {"page_position_equal": bool(np.array_equal(gpos, pos)),
               "attention_max_rel_err": float((np.abs(got - out) / denom).max()),
+              "rel_err_denominator": "max(|want|, 1e-2 * max|want|): elements below 1 % of the largest output are "
+                                     "measured against that floor",
               "output_rounding_half_ulp": 2.0 ** (-8 if a.kv == "bf16" else -11)}
     t0 = time.perf_counter()
     reps = 0
@@ -193,19 +214,81 @@ def cpu_baseline(a, wl, custom_ops, plan_args):
             "ms_per_step_sample": 1e3 * el / reps, "parity_vs_gpu": parity}
 
 
+def kernel_source_stamp():
+    """Short sha256 over the kernel and planner sources: ties a committed HBM-traffic measurement to the code it was
+    taken on, so a number measured on an older kernel is never reported for a newer one."""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "cann-ops-adv-vllm_amd", "csrc")
+    for name in sorted(os.listdir(src)):
+        if name.endswith((".hip", ".inc", ".h", ".cpp")):
+            h.update(name.encode())
+            with open(os.path.join(src, name), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(key):
+    """(HBM bytes per launch, note) from profiles/traffic.json (rocprofv3 --pmc passes, tools/profile_round.sh); the
+    bytes are None when there is no entry for this workload or it was measured on other kernel sources."""
+    tfile = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tfile):
+        return None, "no profiles/traffic.json"
+    try:
+        with open(tfile) as f:
+            rec = json.load(f)
+    except Exception as e:
+        return None, f"profiles/traffic.json unreadable: {e!r}"
+    ent = rec.get(key)
+    if ent is None:
+        return None, "no PMC measurement committed for this workload"
+    stamp = kernel_source_stamp()
+    if ent.get("kernel_source_stamp") != stamp:
+        return None, (f"stale: measured on kernel sources {ent.get('kernel_source_stamp')}, this tree is {stamp} "
+                      "(re-run tools/profile_round.sh)")
+    return ent.get("hbm_bytes_per_launch"), "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes, same sources"
+
+
+def launch_ranks(a):
+    """Parent of a multi-GPU run started as plain `python bench.py --gpus N`: start one rank per GPU under
+    torch.distributed.run and return their exit status.  This process never creates a GPU context (counting the
+    devices does not), so nothing that has touched the GPU is ever replaced or forked."""
+    import socket
+    import subprocess
+    n_dev = torch.cuda.device_count()
+    if n_dev < a.gpus and os.environ.get("BENCH_SINGLE_DEVICE") != "1":
+        print(f"bench.py: --gpus {a.gpus} needs {a.gpus} visible GPUs but this machine shows {n_dev}; "
+              "nothing was run (BENCH_SINGLE_DEVICE=1 BENCH_DIST_BACKEND=gloo rehearses the ranks on one device)",
+              file=sys.stderr)
+        return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a))
     if os.environ.get("BENCH_WATCHDOG"):   # rehearsal aid: dump every thread's stack and exit if the run stalls
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ["BENCH_WATCHDOG"]), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and rank == 0:
+        print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; reporting the {world} rank(s) that exist", file=sys.stderr)
     dist = None
     # Rehearsal on a one-GPU box: BENCH_SINGLE_DEVICE=1 puts every rank on cuda:0 and BENCH_DIST_BACKEND=gloo replaces
     # RCCL (which refuses two ranks on one device); the driver's multi-GPU runs use neither.
     if os.environ.get("BENCH_SINGLE_DEVICE") == "1":
         local_rank = 0
+    backend = "none"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -218,16 +301,13 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     import custom_ops
-    from custom_ops import shard
+    from custom_ops import _abi, shard
 
     if a.no_tail_sharing:
-        from custom_ops import _abi
         _abi.spfaSetTailSharing(0)
     if a.force_tail_sharing:
-        from custom_ops import _abi
         _abi.spfaSetTailSharing(2)
     if a.no_shared_scoring:
-        from custom_ops import _abi
         _abi.spfaSetSharedScoring(0)
     B = a.batch                                     # weak scaling: `batch` sequences per GPU
     wl = build_workload(a, device, B, a.seed + 1000 * rank, custom_ops)
@@ -253,12 +333,14 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # one event in front of every step and one behind the last, all on the launch stream (torch's current stream is
+    # the stream the library enqueues on): their differences are the per-step kernel times
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(a.steps):
+    for i in range(a.steps):
+        evs[i].record()
         step()
-    ev1.record()
+    evs[a.steps].record()
     torch.cuda.synchronize()
     if reducer is not None:
         reducer.wait()
@@ -266,23 +348,24 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / a.steps      # launch-stream events: memset node + fused kernel
+    kernel_ms = evs[0].elapsed_time(evs[a.steps]) / a.steps      # launch-stream events around the fused launches
+    per_step = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(a.steps)])
+    rank_kernel_ms = [kernel_ms]
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        mine = torch.tensor([kernel_ms], dtype=torch.float64, device=device)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rank_kernel_ms = [float(x.item()) for x in every]
     kv_elem = 1 if a.kv == "int8" else 2
     pages, gbytes = gather_bytes(pos, plen, Hkv, Hq // Hkv, wl["page_len"], bs, D, kv_elem)
     achieved = gbytes / (kernel_ms * 1e-3) / 1e9
-    traffic = None
-    tfile = os.path.join(ROOT, "profiles", "traffic.json")   # HBM bytes per launch from rocprofv3 --pmc passes
-    if os.path.exists(tfile):
-        try:
-            rec = json.load(open(tfile))
-            key = f"B{B}_H{Hq}_KV{Hkv}_D{D}_S{a.seqlen}_C{a.clusters}_k{a.topk}_{a.kv}"
-            traffic = rec.get(key, {}).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    traffic, traffic_note = measured_traffic(f"B{B}_H{Hq}_KV{Hkv}_D{D}_S{a.seqlen}_C{a.clusters}_k{a.topk}_{a.kv}")
+    tail = "off (attention_out bit-reproducible)" if a.no_tail_sharing else \
+        "planner default: on for this launch shape when a workgroup has several items (attention_out then agrees " \
+        "between launches to fp32 rounding, <= 2e-6 relative, not bit for bit; integer outputs always bit-identical)"
     result = {
         "metric": "decode tokens/sec + KV HBM GB/s vs roofline, B=64 H=32 D=128 S=32k k=32",
         "value": world * B * a.steps / elapsed, "unit": "tokens/s", "n_gpus": world, "steps": a.steps,
@@ -292,9 +375,18 @@ def main():
                    "batch_per_gpu": B, "global_batch": world * B, "heads": Hq, "kv_heads": Hkv, "head_dim": D,
                    "seq_len": a.seqlen, "clusters": a.clusters, "topk": a.topk, "block_size": bs, "kv_dtype": a.kv,
                    "kv_layout": ("BSH [blocks, block_size, Hkv, D]" if a.kv_layout == "bsh" else "BNSD [blocks, Hkv, block_size, D]"), "kv_pool_GiB": round(2 * wl["key"].numel() * kv_elem / 2 ** 30, 2),
-                   "pages_selected_per_launch": pages, "parallelism": f"batch-shard x{world}"},
+                   "pages_selected_per_launch": pages, "parallelism": f"batch-shard x{world}",
+                   "tail_sharing": tail},
+        "ranks": {"world_size": world, "backend": {"nccl": "rccl"}.get(backend, backend),
+                  "ranks_seen": (dist.get_world_size() if dist is not None else 1),
+                  "kernel_ms_per_rank": rank_kernel_ms,
+                  "collective": ("all_reduce(MAX) of one int64 per step on a side stream" if world > 1 else "none")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": kernel_ms,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
+                     "kernel_ms": kernel_ms,
+                     "kernel_ms_stats": {"min": float(per_step.min()), "median": float(np.median(per_step)),
+                                         "p95": float(np.percentile(per_step, 95)), "max": float(per_step.max()),
+                                         "n": int(a.steps)},
                      "algorithmic_bytes_per_launch": gbytes, "scope": "one GPU (rank 0)"},
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

@@ -41,8 +41,14 @@ struct aclOpExecutor {
     // workspace layout of the two attention ops: [work counters | split arrival counters] (zeroed per launch),
     // split states, per-batch actualSeqLengths
     uint64_t ws_zero_bytes = 0, ws_parts_off = 0, ws_lengths_off = 0, ws_boards_off = 0, ws_tail_off = 0;
-    uint64_t ws_pgdone_off = 0, ws_pgkeys_off = 0;
+    uint64_t ws_pgdone_off = 0, ws_pgkeys_off = 0, ws_batch_off = 0;
     uint64_t ws_bytes = 0;
+    int device = -1;                  // device that was current in phase 1 (-1: none could be queried)
+    // A workspace that only this executor's launches write stays in the state every launch leaves it in (counters,
+    // arrival words and boards zeroed by the last workgroup to exit): the zeroing kernel in front of the launch is
+    // then needed only the first time a workspace is seen.  Opt-in (spfaSetWorkspacePersistent), repeatable executors.
+    bool persistent_ws = false;
+    void* clean_ws = nullptr;
 };
 
 namespace {
@@ -60,6 +66,26 @@ thread_local int64_t g_act_seq_dev_n = 0;
 thread_local void* g_debug_buf = nullptr;   // diagnostic stamp buffer (see spfaSetDebugBuffer)
 
 constexpr size_t kMaxLds = 160 * 1024;    // LDS per CU on gfx950
+
+// The selection knobs (top-k, sink/recent pages, page cap, page size) are one-shot: the next phase 1 of an op that
+// reads them takes them and restores the defaults, whether that call succeeds or not, so a value set for one call can
+// never leak into a later, unrelated call on the same thread.  The launch-planning knobs (split, tail sharing, shared
+// scoring) do not change what is computed beyond fp32 rounding and stay until changed.
+struct SelectionKnobs { int64_t topk; int sink_recent, page_cap; int64_t page_size; };
+SelectionKnobs take_selection_knobs() {
+    const SelectionKnobs k{g_topk, g_sink_recent, g_page_cap, g_page_size};
+    g_topk = 64;
+    g_sink_recent = 0;
+    g_page_cap = 0;
+    g_page_size = 128;
+    return k;
+}
+
+int current_device_or_none() {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    return dev;
+}
 
 aclnnStatus fail(aclnnStatus code, const char* fmt, ...) {
     char buf[512];
@@ -282,6 +308,13 @@ aclnnStatus spfaSetActualSeqLengthsDevice(const int64_t* dev, int64_t n) {
     g_act_seq_dev_n = dev ? n : 0;
     return ACLNN_SUCCESS;
 }
+aclnnStatus spfaSetWorkspacePersistent(aclOpExecutor* e, int enable) {
+    if (!e) return fail(ACLNN_ERR_PARAM_NULLPTR, "executor is NULL");
+    if (enable && !e->repeatable) return fail(ACLNN_ERR_PARAM_INVALID, "only a repeatable executor can keep a workspace");
+    e->persistent_ws = enable != 0;
+    e->clean_ws = nullptr;
+    return ACLNN_SUCCESS;
+}
 // Diagnostic only: device buffer of >= grid*16*16 uint64 that -DSPFA_STAMPS builds fill with cycle stamps.
 __attribute__((visibility("default"))) aclnnStatus spfaSetDebugBuffer(void* dev) { g_debug_buf = dev; return ACLNN_SUCCESS; }
 const char* spfaVersion(void) { return "spfa-hip-gfx950 0.1"; }
@@ -341,6 +374,7 @@ aclnnStatus aclnnSelectPositionGetWorkspaceSize(const aclTensor* blockIds, const
                                                 const aclTensor* pagePositionOut, const aclTensor* pagePositionLengthOut,
                                                 const aclTensor* blockTableGatherOut, uint64_t* workspaceSize,
                                                 aclOpExecutor** executor) {
+    const SelectionKnobs knobs = take_selection_knobs();
     REQUIRE_PTR(workspaceSize, "workspaceSize");
     REQUIRE_PTR(executor, "executor");
     CHECK(check_tensor(indices, "indices", 3, ACL_INT32));
@@ -369,7 +403,7 @@ aclnnStatus aclnnSelectPositionGetWorkspaceSize(const aclTensor* blockIds, const
     p.seq_len = (const int32_t*)data_ptr(seqLen);
     p.indices = (const int32_t*)data_ptr(indices);
     p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.G = Hq / Hkv; p.k = k;
-    p.kv_page_len = kv_page_len; p.max_page = max_page; p.block_size = (int)g_page_size;
+    p.kv_page_len = kv_page_len; p.max_page = max_page; p.block_size = (int)knobs.page_size;
     p.P = (int)pagePositionOut->dims[2];
     p.page_position = (int32_t*)data_ptr(pagePositionOut);
     p.page_position_length = (int32_t*)data_ptr(pagePositionLengthOut);
@@ -393,6 +427,7 @@ aclnnStatus aclnnCentSelectGetWorkspaceSize(const aclTensor* query, const aclTen
                                             const aclTensor* pagePositionOut, const aclTensor* pagePositionLengthOut,
                                             const aclTensor* maxPagePositionLengthOut, uint64_t* workspaceSize,
                                             aclOpExecutor** executor) {
+    const SelectionKnobs knobs = take_selection_knobs();
     REQUIRE_PTR(workspaceSize, "workspaceSize");
     REQUIRE_PTR(executor, "executor");
     int Hq = 0, Hkv = 0, D = 0, C = 0;
@@ -403,7 +438,7 @@ aclnnStatus aclnnCentSelectGetWorkspaceSize(const aclTensor* query, const aclTen
     int B = 0, kv_page_len = 0, max_page = 0;
     CHECK(check_page_tables(blockIds, blockTable, seqLen, Hkv, &B, &kv_page_len, &max_page));
     REQUIRE(query->dims[0] >= B, "query batch %lld < seq_len batch %d", (long long)query->dims[0], B);
-    const int k = (int)g_topk;
+    const int k = (int)knobs.topk;
     REQUIRE(k <= C, "top-k %d exceeds the cluster count %d", k, C);
     CHECK(check_tensor(pagePositionOut, "page_position", 3, ACL_INT32));
     CHECK(check_tensor(pagePositionLengthOut, "page_position_length", 3, ACL_INT32));
@@ -426,9 +461,9 @@ aclnnStatus aclnnCentSelectGetWorkspaceSize(const aclTensor* query, const aclTen
     p.block_ids = (const int32_t*)data_ptr(blockIds);
     p.block_table = (const int32_t*)data_ptr(blockTable);
     p.seq_len = (const int32_t*)data_ptr(seqLen);
-    p.kv_page_len = kv_page_len; p.max_page = max_page; p.block_size = (int)g_page_size;
+    p.kv_page_len = kv_page_len; p.max_page = max_page; p.block_size = (int)knobs.page_size;
     p.P = (int)pagePositionOut->dims[2];
-    p.sink_recent = g_sink_recent; p.cap_pages = g_page_cap;
+    p.sink_recent = knobs.sink_recent; p.cap_pages = knobs.page_cap;
     p.page_position = (int32_t*)data_ptr(pagePositionOut);
     p.page_position_length = (int32_t*)data_ptr(pagePositionLengthOut);
     p.max_page_position_length = (unsigned long long*)data_ptr(maxPagePositionLengthOut);
@@ -695,7 +730,10 @@ static void plan_workspace(aclOpExecutor* e) {
     p.n_split = 1;
     const int n_cu = spfa::device_cu_count();
     long long cap = 0;   // resident workgroups of the kernel this plan selects (no device: 0, no split)
+    e->device = current_device_or_none();
+    p.grid_cap = 0;
     if (n_cu > 0 && items > 0 && spfa::launch_attention(p, nullptr, &cap) != hipSuccess) cap = 0;
+    p.grid_cap = cap;   // phase 2 launches with this: no runtime queries on the launch path
     if (items > 0 && items * 2 <= cap) {
         // One workgroup per CU streams at about half the CU's share of HBM, so fill the idle CUs first; beyond that a
         // second resident workgroup per CU still helps (measured: 256 items 0.150 -> 0.146 ms), more shares per item
@@ -733,7 +771,9 @@ static void plan_workspace(aclOpExecutor* e) {
     p.pg_on = n_groups > 0 ? 1 : 0;
     e->ws_boards_off = kCounterBytes + (p.n_split > 1 ? up256((uint64_t)items * 4) : 0);
     e->ws_pgdone_off = e->ws_boards_off + up256(n_boards * 16);
-    e->ws_zero_bytes = e->ws_pgdone_off + up256(n_groups * 4);
+    e->ws_batch_off = e->ws_pgdone_off + up256(n_groups * 4);   // per-batch arrival counts [B] u32, then maxima [B] u64
+    const uint64_t batch_words = (p.mode == 1 && p.max_page_position_length) ? (uint64_t)p.B : 0;
+    e->ws_zero_bytes = e->ws_batch_off + up256(batch_words * 4) + up256(batch_words * 8);
     e->ws_parts_off = e->ws_zero_bytes;
     const uint64_t parts = p.n_split > 1 ? up256((uint64_t)items * p.n_split * state_bytes) : 0;
     e->ws_tail_off = e->ws_parts_off + parts;
@@ -742,19 +782,29 @@ static void plan_workspace(aclOpExecutor* e) {
     e->ws_bytes = e->ws_lengths_off + (e->act_seq.empty() ? 0 : up256((uint64_t)p.B * 8));
 }
 
-// Bind the planned workspace layout to the caller's buffer and enqueue the zeroing of its counters.
-static hipError_t bind_workspace(const aclOpExecutor* e, spfa::AttnParams& p, void* workspace, hipStream_t stream,
-                                 void* also_zero = nullptr, size_t also_bytes = 0) {
+// Bind the planned workspace layout to the caller's buffer and (zero: unless the buffer is known to be in the state
+// the previous launch left it in) enqueue the zeroing of its counters.
+static hipError_t bind_workspace(const aclOpExecutor* e, spfa::AttnParams& p, void* workspace, hipStream_t stream, bool zero) {
     if (((uintptr_t)workspace & 15) != 0) return hipErrorInvalidValue;   // 64-bit atomics and 16-byte boards live in it
+    auto up256 = [](uint64_t x) { return (x + 255) & ~255ull; };
     p.counters = (unsigned*)workspace;
+    p.zero_words = e->ws_zero_bytes / 8;
     p.split_done = (unsigned*)((char*)workspace + kCounterBytes);
     p.split_partials = (float*)((char*)workspace + e->ws_parts_off);
     p.tail_boards = (char*)workspace + e->ws_boards_off;
     p.tail_data = (char*)workspace + e->ws_tail_off;
     p.pg_done = (unsigned*)((char*)workspace + e->ws_pgdone_off);
     p.pg_keys = (uint32_t*)((char*)workspace + e->ws_pgkeys_off);
-    // (+ the per-batch maxima of the fused op, accumulated with atomicMax) in one small kernel
-    return spfa::launch_zero(workspace, e->ws_zero_bytes, also_zero, also_bytes, stream);
+    p.batch_arrive = (unsigned*)((char*)workspace + e->ws_batch_off);
+    p.batch_max = (unsigned long long*)((char*)workspace + e->ws_batch_off + up256((uint64_t)p.B * 4));
+    return zero ? spfa::launch_zero(workspace, e->ws_zero_bytes, nullptr, 0, stream) : hipSuccess;
+}
+
+// Phase 2 runs on the device phase 1 planned for (grid size, LDS limit and residency belong to that device).
+static aclnnStatus check_device(const aclOpExecutor* e) {
+    const int now = current_device_or_none();
+    REQUIRE(e->device < 0 || now == e->device, "executor was planned on device %d but device %d is current", e->device, now);
+    return ACLNN_SUCCESS;
 }
 
 #define REJECT_PRESENT(t, name) \
@@ -768,6 +818,11 @@ aclnnStatus aclnnSparsePagedAttentionGetWorkspaceSize(
     const aclTensor* blocktable, const aclTensor* kvPaddingSize, const aclTensor* blockposition, int64_t numHeads,
     double scaleValue, char* inputLayout, int64_t numKeyValueHeads, int64_t blockSize, int64_t /*innerPrecise*/,
     const aclTensor* attentionOut, uint64_t* workspaceSize, aclOpExecutor** executor) {
+    // one-shot: taken before anything can fail, so a rejected call never leaves a device pointer armed for the next one
+    const long long* const act_seq_dev = g_act_seq_dev;
+    const int64_t act_seq_dev_n = g_act_seq_dev_n;
+    g_act_seq_dev = nullptr;
+    g_act_seq_dev_n = 0;
     REQUIRE_PTR(workspaceSize, "workspaceSize");
     REQUIRE_PTR(executor, "executor");
     REJECT_PRESENT(dequantScale1, "dequantScale1");   // int8 queries are not part of this path
@@ -793,12 +848,11 @@ aclnnStatus aclnnSparsePagedAttentionGetWorkspaceSize(
     p.P = (int)blockposition->dims[2];
     p.max_entries = p.P;
     p.act_seq_uniform = -1;
-    if (g_act_seq_dev) {   // extension: lengths already on the device, no host round trip
-        if (g_act_seq_dev_n < p.B)
+    if (act_seq_dev) {   // extension: lengths already on the device, no host round trip
+        if (act_seq_dev_n < p.B)
             return bail(fail(ACLNN_ERR_PARAM_INVALID, "device actualSeqLengths has %lld values < batch %d",
-                             (long long)g_act_seq_dev_n, p.B));
-        p.act_seq = g_act_seq_dev;
-        g_act_seq_dev = nullptr;
+                             (long long)act_seq_dev_n, p.B));
+        p.act_seq = act_seq_dev;
     } else if (actualSeqLengths && !actualSeqLengths->v.empty()) {
         const auto& v = actualSeqLengths->v;
         if (v.size() != 1 && (int)v.size() < p.B)
@@ -831,26 +885,17 @@ aclnnStatus aclnnSparsePagedAttention(void* workspace, uint64_t workspaceSize, a
         if (!executor->repeatable) delete executor;
         return fail(ACLNN_ERR_PARAM_INVALID, "workspace of %llu bytes required", need);
     }
-    hipError_t err = bind_workspace(executor, p, workspace, (hipStream_t)stream);
+    {
+        const aclnnStatus ds = check_device(executor);
+        if (ds != ACLNN_SUCCESS) { if (!executor->repeatable) delete executor; return ds; }
+    }
+    hipError_t err = bind_workspace(executor, p, workspace, (hipStream_t)stream, true);
     if (err == hipSuccess && !executor->act_seq.empty()) {
-        void* lengths = (char*)workspace + executor->ws_lengths_off;
-        // Per-batch lengths travel through the workspace.  A one-shot executor dies when this call
-        // returns, so its host copy is handed to the stream and freed there after the copy ran.
-        const long long* src = executor->act_seq.data();
-        std::vector<long long>* parked = nullptr;
-        if (!executor->repeatable) {
-            parked = new std::vector<long long>(std::move(executor->act_seq));
-            src = parked->data();
-        }
-        err = hipMemcpyAsync(lengths, src, (size_t)p.B * 8, hipMemcpyHostToDevice, (hipStream_t)stream);
-        if (parked) {
-            hipError_t e2 = hipLaunchHostFunc((hipStream_t)stream, [](void* v) { delete (std::vector<long long>*)v; }, parked);
-            if (e2 != hipSuccess) {   // could not enqueue the release: wait, then free here
-                (void)hipStreamSynchronize((hipStream_t)stream);
-                delete parked;
-            }
-        }
-        p.act_seq = (const long long*)lengths;
+        // Per-batch lengths travel to the workspace as kernel arguments: copied when the launch is enqueued (or
+        // captured into a graph), so no host memory has to outlive this call.
+        long long* lengths = (long long*)((char*)workspace + executor->ws_lengths_off);
+        err = spfa::launch_store_lengths(lengths, executor->act_seq.data(), p.B, (hipStream_t)stream);
+        p.act_seq = lengths;
     }
     if (err == hipSuccess) err = spfa::launch_attention(p, (hipStream_t)stream);
     return finish(executor, err, "sparse_paged_attention launch");
@@ -866,6 +911,7 @@ aclnnStatus aclnnSparsePagedFusionAttentionGetWorkspaceSize(
     int64_t blockSize, int64_t /*innerPrecise*/, const aclTensor* block_position, const aclTensor* page_position_length,
     const aclTensor* max_page_position_length, const aclTensor* attentionOut, uint64_t* workspaceSize,
     aclOpExecutor** executor) {
+    const SelectionKnobs knobs = take_selection_knobs();
     REQUIRE_PTR(workspaceSize, "workspaceSize");
     REQUIRE_PTR(executor, "executor");
     REJECT_PRESENT(dequantScale1, "dequantScale1");   // int8 queries are not part of this path
@@ -888,13 +934,13 @@ aclnnStatus aclnnSparsePagedFusionAttentionGetWorkspaceSize(
     if (p.Hkv != Hkv || p.D != D)
         return bail(fail(ACLNN_ERR_PARAM_INVALID, "l1_cent [%d, %d, %d] does not match numKeyValueHeads %d / head dim %d",
                          Hkv, C, D, p.Hkv, p.D));
-    const int k = (int)g_topk;
+    const int k = (int)knobs.topk;
     if (k > C) return bail(fail(ACLNN_ERR_PARAM_INVALID, "top-k %d exceeds the cluster count %d", k, C));
     p.cent = data_ptr(l1_cent);
     p.block_ids = (const int32_t*)data_ptr(block_ids);
     p.seq_len = (const int32_t*)data_ptr(total_seq_len);
     p.C = C; p.Cp = round_up(C, 128); p.k = k; p.kv_page_len = kv_page_len;
-    p.sink_recent = g_sink_recent; p.cap_pages = g_page_cap;
+    p.sink_recent = knobs.sink_recent; p.cap_pages = knobs.page_cap;
     p.P = max_page;
     if (!absent(block_position)) {
         st = check_tensor(block_position, "block_position", 3, ACL_INT32);
@@ -940,9 +986,14 @@ aclnnStatus aclnnSparsePagedFusionAttention(void* workspace, uint64_t workspaceS
         if (!executor->repeatable) delete executor;
         return fail(ACLNN_ERR_PARAM_INVALID, "workspace of %llu bytes required", need);
     }
-    hipError_t err = bind_workspace(executor, p, workspace, (hipStream_t)stream, p.max_page_position_length,
-                                    p.max_page_position_length ? (size_t)p.B * spfa::kLenPad * 8 : 0);
+    {
+        const aclnnStatus ds = check_device(executor);
+        if (ds != ACLNN_SUCCESS) { if (!executor->repeatable) delete executor; return ds; }
+    }
+    const bool known_clean = executor->repeatable && executor->persistent_ws && executor->clean_ws == workspace;
+    hipError_t err = bind_workspace(executor, p, workspace, (hipStream_t)stream, !known_clean);
     if (err == hipSuccess) err = spfa::launch_attention(p, (hipStream_t)stream);
+    if (executor->repeatable) executor->clean_ws = err == hipSuccess ? workspace : nullptr;
     return finish(executor, err, "sparse_paged_fusion_attention launch");
 }
 

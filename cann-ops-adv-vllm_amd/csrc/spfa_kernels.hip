@@ -109,37 +109,58 @@ __device__ __forceinline__ float load_qk_elem(const void* p, int dtype, long lon
 #include "spfa_stream_mfma.inc"
 #include "spfa_attn_kernel.inc"
 
+constexpr int kMaxDevices = 64;
+// Raise a kernel's dynamic-LDS limit on the current device when `bytes` exceeds what was set before (the limit is a
+// property of the kernel on a device, and executors planned with different sizes may be launched in any order).
+// `table` holds the limit already set per device.
+hipError_t ensure_lds_limit(const void* kern, int* table, size_t bytes) {
+    if (bytes <= 48 * 1024) return hipSuccess;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= kMaxDevices) return hipErrorInvalidDevice;
+    if (__atomic_load_n(&table[dev], __ATOMIC_ACQUIRE) >= (int)bytes) return hipSuccess;
+    e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return e;
+    int seen = __atomic_load_n(&table[dev], __ATOMIC_RELAXED);
+    while (seen < (int)bytes && !__atomic_compare_exchange_n(&table[dev], &seen, (int)bytes, false, __ATOMIC_RELEASE,
+                                                              __ATOMIC_RELAXED)) {}
+    return hipSuccess;
+}
+
+// cap_out != nullptr (phase 1): set the LDS limit, ask the runtime how many workgroups fit a CU, report the resident
+// grid.  Otherwise (phase 2): launch; with p.grid_cap from phase 1 this is nothing but the launch itself.
 template <typename KVT, int NQ, int LPT, bool MFMA>
 hipError_t launch_attn_one(const AttnParams& p, hipStream_t s, long long* cap_out) {
     auto kern = attn_kernel<KVT, NQ, LPT, MFMA>;
-    if (p.lds_bytes > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)p.lds_bytes);
+    static int lds_limit[kMaxDevices];
+    long long cap = p.grid_cap;
+    if (cap_out || cap <= 0) {
+        hipError_t e = ensure_lds_limit((const void*)kern, lds_limit, p.lds_bytes);
         if (e != hipSuccess) return e;
+        int occ = 0;
+        const int n_cu = device_cu_count();
+        if (n_cu <= 0) return hipErrorNoDevice;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, attn_threads(MFMA, sizeof(KVT) == 1), p.lds_bytes);
+        if (e != hipSuccess) return e;
+        int blocks_per_cu = occ < 1 ? 1 : occ;   // residency of the persistent grid
+        // 8 streamer waves per CU already saturate HBM; a third workgroup only deepens the memory queues
+        if (blocks_per_cu > SPFA_WGS_PER_CU) blocks_per_cu = SPFA_WGS_PER_CU;
+        cap = (long long)n_cu * blocks_per_cu;
+        static bool said = false;
+        if (!said && getenv("SPFA_DEBUG")) {
+            said = true;
+            fprintf(stderr, "[spfa] attn blocks/CU=%d CUs=%d lds=%zu mfma=%d\n", blocks_per_cu, n_cu, p.lds_bytes, (int)MFMA);
+        }
     }
-    int occ = 0;
-    const int n_cu = device_cu_count();
-    if (n_cu <= 0) return hipErrorNoDevice;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, attn_threads(MFMA, sizeof(KVT) == 1), p.lds_bytes);
-    if (e != hipSuccess) return e;
-    int blocks_per_cu = occ < 1 ? 1 : occ;   // residency of the persistent grid
-    // 8 streamer waves per CU already saturate HBM; a third workgroup only deepens the memory queues
-    if (blocks_per_cu > SPFA_WGS_PER_CU) blocks_per_cu = SPFA_WGS_PER_CU;
+    if (cap_out) { *cap_out = cap; return hipSuccess; }   // planning: how many workgroups can be resident
     const bool per_head = (p.mode == 0 && p.pos_rows == p.Hq && p.G > 1);
     const int g_eff = per_head ? 1 : p.G;
     const int nq = MFMA ? p.rows_per_pass : NQ;
     const long long total = (long long)p.B * (per_head ? p.Hq : p.Hkv) * ((g_eff + nq - 1) / nq) * p.n_split;
-    if (total == 0 && !cap_out) return hipSuccess;
-    const long long cap = (long long)n_cu * blocks_per_cu;
-    if (cap_out) { *cap_out = cap; return hipSuccess; }   // planning: how many workgroups can be resident
+    if (total == 0) return hipSuccess;
     if (p.n_split > 1 && total > cap) return hipErrorInvalidConfiguration;   // a split needs one workgroup per unit
     const dim3 grid((unsigned)(total < cap ? total : cap));
-    static bool said = false;
-    if (!said && getenv("SPFA_DEBUG")) {
-        said = true;
-        fprintf(stderr, "[spfa] attn grid=%u blocks/CU=%d CUs=%d lds=%zu items=%lld mfma=%d\n", grid.x, blocks_per_cu, n_cu,
-                p.lds_bytes, total, (int)MFMA);
-    }
     hipLaunchKernelGGL(kern, grid, dim3(attn_threads(MFMA, sizeof(KVT) == 1)), p.lds_bytes, s, p);
     return hipGetLastError();
 }
@@ -194,6 +215,26 @@ hipError_t launch_zero(void* a, size_t a_bytes, void* b, size_t b_bytes, hipStre
     const unsigned blocks = (unsigned)((most + 255) / 256 < 64 ? (most + 255) / 256 : 64);
     hipLaunchKernelGGL(zero_kernel, dim3(blocks), dim3(256), 0, s, (unsigned long long*)a, na, (unsigned long long*)b, nb);
     return hipGetLastError();
+}
+
+// Per-batch lengths as kernel arguments: up to kLengthsPerLaunch values per launch (3.5 KiB of the 4 KiB argument space).
+constexpr int kLengthsPerLaunch = 448;
+struct LengthPack { long long v[kLengthsPerLaunch]; };
+__global__ void store_lengths_kernel(long long* dst, const LengthPack pack, int n) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i < n) dst[i] = pack.v[i];
+}
+hipError_t launch_store_lengths(long long* dst, const long long* host, int n, hipStream_t s) {
+    for (int base = 0; base < n; base += kLengthsPerLaunch) {
+        LengthPack pack;
+        const int m = n - base < kLengthsPerLaunch ? n - base : kLengthsPerLaunch;
+        for (int i = 0; i < m; ++i) pack.v[i] = host[base + i];
+        for (int i = m; i < kLengthsPerLaunch; ++i) pack.v[i] = 0;
+        hipLaunchKernelGGL(store_lengths_kernel, dim3((m + 255) / 256), dim3(256), 0, s, dst + base, pack, m);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 int device_cu_count() {
@@ -263,10 +304,9 @@ static hipError_t launch_cent(const CentParams& p, int mode, hipStream_t s) {
     const dim3 grid((unsigned)((long long)((p.B + p.seq_per_group - 1) / p.seq_per_group) * p.Hkv));
     if (grid.x == 0) return hipSuccess;
     const void* kern = mode == 0 ? (const void*)cent_kernel<0> : (const void*)cent_kernel<1>;
-    if (p.lds_bytes > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
-        if (e != hipSuccess) return e;
-    }
+    static int lds_limit[2][kMaxDevices];
+    const hipError_t le = ensure_lds_limit(kern, lds_limit[mode], p.lds_bytes);
+    if (le != hipSuccess) return le;
     if (mode == 0) hipLaunchKernelGGL(cent_kernel<0>, grid, dim3(kThreads), p.lds_bytes, s, p);
     else hipLaunchKernelGGL(cent_kernel<1>, grid, dim3(kThreads), p.lds_bytes, s, p);
     return hipGetLastError();

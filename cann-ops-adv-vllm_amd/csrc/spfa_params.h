@@ -95,7 +95,17 @@ struct AttnParams {
     int P;                         // slots per row (both modes)
     int rows_per_pass;             // q heads of a group handled per pass
     int max_entries;               // capacity of the per-workgroup page list
-    unsigned* counters;            // 8 work counters (workspace), zeroed before every launch
+    unsigned* counters;            // start of the workspace: 8 work counters, [8] = workgroups that have left the kernel
+    // The part of the workspace that every launch expects zeroed (counters, arrival words, boards): zero_words 8-byte
+    // words from `counters` on.  The last workgroup to leave a launch zeroes it again, so a workspace that nobody
+    // else writes needs the zeroing kernel only before its first launch.
+    unsigned long long zero_words;
+    // per-batch maximum of the fused op (cent_select.cpp:124-152) without pre-zeroed output: every item adds its
+    // longest list to batch_max[b] and its row count to batch_arrive[b]; the item that completes the Hq rows of a
+    // batch stores max_page_position_length[b, 0..7]
+    unsigned* batch_arrive;        // [B] (workspace, zeroed)
+    unsigned long long* batch_max; // [B] (workspace, zeroed)
+    long long grid_cap;            // resident workgroups of the selected kernel on the planning device (phase 1); 0: ask at launch
     // 0: a workgroup claims items of its own XCD's class (item % 8) as long as there are any, so the kv heads an XCD
     // works on stay the same (centroids in its L2); 1: every claim starts one class further, which mixes heads whose
     // page lists are systematically longer or shorter over all XCDs
@@ -127,6 +137,9 @@ hipError_t launch_select_position(const SelectParams& p, hipStream_t s);
 hipError_t launch_attention(const AttnParams& p, hipStream_t s, long long* cap_out = nullptr);
 // Enqueue the zeroing of up to two 8-byte aligned ranges (either may be null / empty) as one small kernel.
 hipError_t launch_zero(void* a, size_t a_bytes, void* b, size_t b_bytes, hipStream_t s);
+// Enqueue dst[0..n) = host[0..n): the values travel as kernel arguments (copied when the launch is enqueued or captured),
+// so the host array may die as soon as the call returns and nothing is allocated or waited for.
+hipError_t launch_store_lengths(long long* dst, const long long* host, int n, hipStream_t s);
 // Compute units of the current device (0 when no device can be queried).
 int device_cu_count();
 // Number of q heads of a group one pass over the K/V pages serves, and whether that pass runs on the MFMA streamer

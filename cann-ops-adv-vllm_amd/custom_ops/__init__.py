@@ -4,10 +4,10 @@ from .add_custom import (PreparedFusion, cent_select, compute_cent, incre_flash_
                          sparse_paged_attention, sparse_paged_fusion_attention)
 
 __all__ = ["PreparedFusion", "cent_select", "compute_cent", "incre_flash_attention_v4", "select_position",
-           "sparse_paged_attention", "sparse_paged_fusion_attention"]
+           "sparse_paged_attention", "sparse_paged_fusion_attention", "set_dispatch_defaults"]
 
 # torch.ops.myops.* (the reference registers its schemas when its extension is imported,
 # extension/csrc/registration.cpp:43-57)
-from .registration import register as _register  # noqa: E402
+from .registration import register as _register, set_dispatch_defaults  # noqa: E402,F401
 
 _register()

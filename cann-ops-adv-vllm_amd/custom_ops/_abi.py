@@ -59,6 +59,7 @@ spfaSetTailSharing = _sig("spfaSetTailSharing", c_int, [c_int])
 spfaSetSharedScoring = _sig("spfaSetSharedScoring", c_int, [c_int])
 spfaSetPageSize = _sig("spfaSetPageSize", c_int, [c_int64])
 spfaSetActualSeqLengthsDevice = _sig("spfaSetActualSeqLengthsDevice", c_int, [c_void_p, c_int64])
+spfaSetWorkspacePersistent = _sig("spfaSetWorkspacePersistent", c_int, [T, c_int])
 spfaVersion = _sig("spfaVersion", c_char_p, [])
 
 _WS = [POINTER(c_uint64), POINTER(T)]          # uint64_t* workspaceSize, aclOpExecutor** executor
@@ -138,13 +139,15 @@ def run(get_ws, exe, args, device, what, keep=()):
     (EXEC_NPU_CMD, pytorch_npu_helper.hpp:721-799)."""
     ws_size = c_uint64(0)
     executor = T()
-    check(get_ws(*args, ctypes.byref(ws_size), ctypes.byref(executor)), what + "GetWorkspaceSize")
     ws = None
     ws_ptr = c_void_p(0)
-    if ws_size.value > 0:
-        ws = torch.empty(ws_size.value, dtype=torch.uint8, device=device)
-        ws_ptr = c_void_p(ws.data_ptr())
+    # both phases run with the tensors' device current: phase 1 plans for the current device (CU count, residency,
+    # LDS limit of the kernel) and phase 2 refuses to launch on another one
     with torch.cuda.device(device):
+        check(get_ws(*args, ctypes.byref(ws_size), ctypes.byref(executor)), what + "GetWorkspaceSize")
+        if ws_size.value > 0:
+            ws = torch.empty(ws_size.value, dtype=torch.uint8, device=device)
+            ws_ptr = c_void_p(ws.data_ptr())
         status = exe(ws_ptr, ws_size.value, executor, current_stream(device))
     if ws is not None:
         ws.record_stream(torch.cuda.current_stream(device))

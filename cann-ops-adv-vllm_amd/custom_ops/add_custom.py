@@ -5,7 +5,8 @@ extension/custom_ops/add_custom.py (:41-135); every call goes through the aclnn-
 libcust_opapi.so on torch's current HIP stream.  Optional operands follow the reference's
 convention: an empty tensor (numel() == 0) means "absent" (extension/csrc/add_custom.cpp:32-35).
 
-Keyword-only extras (not in the reference, which hard-codes them):
+Keyword-only extras (not in the reference, which hard-codes them; they travel through one-shot per-thread settings of
+the C-ABI that the very next phase 1 consumes):
   k             top-k clusters (reference: 64, add_custom.cpp:940 / cent_select_tiling.cpp:58)
   sink_recent   also select logical pages 0, pageLen-2, pageLen-1 (cent_select.cpp:350-362)
   max_pages_cap clip page_position_length to pageLen // 8 (cent_select.cpp:218,410-414)
@@ -72,9 +73,9 @@ def select_position(block_ids: torch.Tensor, block_table: torch.Tensor, seq_len:
     pos = torch.empty((B, Hq, int(max_page_num)), dtype=torch.int32, device=dev)
     length = torch.empty((B, Hq, 8), dtype=torch.int32, device=dev)
     gather = torch.empty((B, Hq, block_table.shape[1]), dtype=torch.int32, device=dev)
-    _set_knobs(page_size=page_size)
     descs = [_abi.to_acl(t) for t in (block_ids, block_table, seq_len, indices, pos, length, gather)]
     try:
+        _set_knobs(page_size=page_size)   # one-shot settings: right in front of the phase 1 that consumes them
         _abi.run(_abi.aclnnSelectPositionGetWorkspaceSize, _abi.aclnnSelectPosition, descs, dev, "aclnnSelectPosition")
     finally:
         _destroy(descs)
@@ -93,11 +94,11 @@ def cent_select(query: torch.Tensor, l1_cent: torch.Tensor, block_ids: torch.Ten
     pos = torch.empty((B, Hq, int(max_page_num)), dtype=torch.int32, device=dev)
     length = torch.empty((B, Hq, 8), dtype=torch.int32, device=dev)
     max_len = torch.empty((B, 8), dtype=torch.int64, device=dev)
-    _set_knobs(k, sink_recent, max_pages_cap, page_size)
     descs = [_abi.to_acl(t) for t in (query, l1_cent, block_ids, block_table, seq_len)]
     descs += [None]  # importance: allocated but never read by the reference (add_custom.cpp:995)
     descs += [_abi.to_acl(t) for t in (pos, length, max_len)]
     try:
+        _set_knobs(k, sink_recent, max_pages_cap, page_size)
         _abi.run(_abi.aclnnCentSelectGetWorkspaceSize, _abi.aclnnCentSelect, descs, dev, "aclnnCentSelect")
     finally:
         _destroy(descs)
@@ -144,22 +145,26 @@ def sparse_paged_attention(query: torch.Tensor, key: torch.Tensor, value: torch.
     _abi.require_gpu(query, key, value, blocktable, blockposition)
     dev = query.device
     out = torch.empty(query.shape, dtype=out_dtype or _default_out_dtype(query, quant_scale2), device=dev)
-    seq_arr, dev_lengths = _seq_lengths_arg(actual_seq_lengths, dev)
-    tens = [_abi.to_acl(t) for t in (query,)]
-    kl, vl = _abi.to_acl_list([key]), _abi.to_acl_list([value])
-    opt = [_abi.to_acl(t) for t in (pse_shift, attention_mask)]
-    quant = [_abi.to_acl(t) for t in (dequant_scale1, quant_scale1, dequant_scale2, quant_scale2, quant_offset2,
-                                      antiquant_scale, antiquant_offset, blocktable, kv_padding_size, blockposition)]
-    out_d = _abi.to_acl(out)
-    args = tens + [kl, vl] + opt + [seq_arr] + quant + [
-        int(num_heads), float(scale_value), str(input_layout).encode(), int(num_key_value_heads), int(block_size),
-        int(inner_precise), out_d]
+    tens, opt, quant, lists, arrays, dev_lengths = [], [], [], [], [], None
     try:
+        tens = [_abi.to_acl(query)]
+        lists = [_abi.to_acl_list([key]), _abi.to_acl_list([value])]
+        opt = [_abi.to_acl(t) for t in (pse_shift, attention_mask)]
+        quant = [_abi.to_acl(t) for t in (dequant_scale1, quant_scale1, dequant_scale2, quant_scale2, quant_offset2,
+                                          antiquant_scale, antiquant_offset, blocktable, kv_padding_size,
+                                          blockposition)]
+        tens.append(_abi.to_acl(out))
+        # last, right in front of phase 1 (which consumes it): the device-resident lengths are a one-shot setting
+        seq_arr, dev_lengths = _seq_lengths_arg(actual_seq_lengths, dev)
+        arrays = [seq_arr]
+        args = tens[:1] + lists + opt + [seq_arr] + quant + [
+            int(num_heads), float(scale_value), str(input_layout).encode(), int(num_key_value_heads), int(block_size),
+            int(inner_precise), tens[1]]
         _abi.run(_abi.aclnnSparsePagedAttentionGetWorkspaceSize, _abi.aclnnSparsePagedAttention, args, dev,
                  "aclnnSparsePagedAttention")
     finally:
         _abi.spfaSetActualSeqLengthsDevice(None, 0)
-        _destroy(tens + opt + quant + [out_d], [kl, vl], [seq_arr])
+        _destroy(tens + opt + quant, lists, arrays)
     if dev_lengths is not None:
         dev_lengths.record_stream(torch.cuda.current_stream(dev))
     return out
@@ -186,7 +191,6 @@ def sparse_paged_fusion_attention(query: torch.Tensor, key: torch.Tensor, value:
     _abi.require_gpu(query, key, value, blocktable, l1_cent, block_ids, total_seq_len)
     dev = query.device
     out = torch.empty(query.shape, dtype=out_dtype or _default_out_dtype(query, quant_scale2), device=dev)
-    _set_knobs(k, sink_recent, max_pages_cap)
     tens = [_abi.to_acl(query)]
     kl, vl = _abi.to_acl_list([key]), _abi.to_acl_list([value])
     mid = [_abi.to_acl(t) for t in (pse_shift, attention_mask)]
@@ -198,6 +202,7 @@ def sparse_paged_fusion_attention(query: torch.Tensor, key: torch.Tensor, value:
         int(num_heads), float(scale_value), str(input_layout).encode(), int(num_key_value_heads), int(block_size),
         int(inner_precise)] + outs
     try:
+        _set_knobs(k, sink_recent, max_pages_cap)
         _abi.run(_abi.aclnnSparsePagedFusionAttentionGetWorkspaceSize, _abi.aclnnSparsePagedFusionAttention, args,
                  dev, "aclnnSparsePagedFusionAttention")
     finally:
@@ -214,14 +219,13 @@ class PreparedFusion:
     def __init__(self, query, key, value, blocktable, l1_cent, block_ids, total_seq_len, block_position,
                  page_position_length, max_page_position_length, num_heads, scale_value, num_key_value_heads,
                  block_size, *, antiquant_scale=None, antiquant_offset=None, k=64, sink_recent=False,
-                 max_pages_cap=False, out_dtype=None, input_layout="BNSD"):
+                 max_pages_cap=False, out_dtype=None, input_layout="BNSD", persistent_workspace=True):
         import ctypes
         _abi.require_gpu(query, key, value, blocktable, l1_cent, block_ids, total_seq_len)
         self.device = query.device
         self.out = torch.empty(query.shape, dtype=out_dtype or query.dtype, device=self.device)
         self._keep = (query, key, value, blocktable, l1_cent, block_ids, total_seq_len, block_position,
                       page_position_length, max_page_position_length, antiquant_scale, antiquant_offset)
-        _set_knobs(k, sink_recent, max_pages_cap)
         tens = [_abi.to_acl(query)]
         kl, vl = _abi.to_acl_list([key]), _abi.to_acl_list([value])
         rest = [None] * 5 + [_abi.to_acl(t) for t in (antiquant_scale, antiquant_offset, blocktable)] + [None] + \
@@ -233,20 +237,28 @@ class PreparedFusion:
         ws_size = ctypes.c_uint64(0)
         self._exec = _abi.T()
         try:
-            _abi.check(_abi.aclnnSparsePagedFusionAttentionGetWorkspaceSize(*args, ctypes.byref(ws_size),
-                                                                            ctypes.byref(self._exec)),
-                       "aclnnSparsePagedFusionAttentionGetWorkspaceSize")
+            with torch.cuda.device(self.device):   # the plan is made for, and bound to, the tensors' device
+                _set_knobs(k, sink_recent, max_pages_cap)
+                _abi.check(_abi.aclnnSparsePagedFusionAttentionGetWorkspaceSize(*args, ctypes.byref(ws_size),
+                                                                                ctypes.byref(self._exec)),
+                           "aclnnSparsePagedFusionAttentionGetWorkspaceSize")
         finally:
             _destroy(tens + rest + outs, [kl, vl])
         _abi.check(_abi.aclSetAclOpExecutorRepeatable(self._exec), "aclSetAclOpExecutorRepeatable")
         self._ws = torch.empty(max(int(ws_size.value), 1), dtype=torch.uint8, device=self.device)
         self._ws_size = int(ws_size.value)
+        # the workspace belongs to this plan alone, so its counters stay as every launch leaves them (zeroed): after
+        # the first launch each run() is exactly one kernel
+        _abi.check(_abi.spfaSetWorkspacePersistent(self._exec, 1 if persistent_workspace else 0),
+                   "spfaSetWorkspacePersistent")
 
     def run(self) -> torch.Tensor:
         """Enqueue one fused launch on torch's current stream; returns the (reused) output tensor."""
-        _abi.check(_abi.aclnnSparsePagedFusionAttention(self._ws.data_ptr() if self._ws_size else None,
-                                                        self._ws_size, self._exec, _abi.current_stream(self.device)),
-                   "aclnnSparsePagedFusionAttention")
+        with torch.cuda.device(self.device):
+            _abi.check(_abi.aclnnSparsePagedFusionAttention(self._ws.data_ptr() if self._ws_size else None,
+                                                            self._ws_size, self._exec,
+                                                            _abi.current_stream(self.device)),
+                       "aclnnSparsePagedFusionAttention")
         return self.out
 
     def close(self):

@@ -91,6 +91,11 @@ SPFA_API void ReleaseHugeMem(void* arg, bool sync);
  * pageLen/8 cap: cent_select.cpp:218,350-362,410-414).  Defaults: k = 64, sink_recent = 0,
  * cap_pages = 0 (the reference's Python/CPU path).
  */
+/* The four selection knobs below are ONE-SHOT: the next aclnn<Op>GetWorkspaceSize of an op that reads them
+ * (CentSelect, SelectPosition: page size only, SparsePagedFusionAttention) takes them and restores the defaults,
+ * whether that call succeeds or fails.  A C caller that wants the device kernel's behaviour of the reference
+ * (cent_select.cpp: k = 64, sink/recent pages, pageLen/8 cap) calls spfaSetSinkRecent(1); spfaSetPageCap(1); before
+ * every phase 1. */
 SPFA_API aclnnStatus spfaSetTopK(int64_t k);
 SPFA_API aclnnStatus spfaSetSinkRecent(int enable);
 SPFA_API aclnnStatus spfaSetPageCap(int enable);
@@ -115,6 +120,12 @@ SPFA_API aclnnStatus spfaSetPageSize(int64_t pageSize);
  * from this DEVICE array of n int64 instead of the host aclIntArray (the reference's binding copies a
  * device tensor to the host first, add_custom.cpp:105-118). */
 SPFA_API aclnnStatus spfaSetActualSeqLengthsDevice(const int64_t* deviceLengths, int64_t n);
+/* A launch of the two attention ops starts with a small kernel that zeroes the counters at the head of the workspace;
+ * the op's kernel leaves them zeroed again when it ends.  enable = 1 on a repeatable executor of
+ * SparsePagedFusionAttention promises that nothing but this executor's launches writes the workspace between
+ * them: the zeroing kernel then runs only the first time a workspace pointer is seen, and every later call is exactly
+ * one kernel launch.  Default 0 (the workspace is scratch that the caller may reuse between calls). */
+SPFA_API aclnnStatus spfaSetWorkspacePersistent(aclOpExecutor* executor, int enable);
 SPFA_API const char* spfaVersion(void);
 
 #ifdef __cplusplus

@@ -30,6 +30,8 @@ def lib():
     L.aclnnSparsePagedAttentionGetWorkspaceSize.argtypes = [T] * 16 + attrs + [T, POINTER(c_uint64), POINTER(T)]
     L.aclnnSparsePagedFusionAttentionGetWorkspaceSize.argtypes = [T] * 18 + attrs + [T] * 4 + [POINTER(c_uint64), POINTER(T)]
     L.aclnnCentSelectGetWorkspaceSize.argtypes = [T] * 9 + [POINTER(c_uint64), POINTER(T)]
+    L.spfaSetTopK.argtypes = [c_int64]
+    L.spfaSetActualSeqLengthsDevice.argtypes = [c_void_p, c_int64]
     return L
 
 
@@ -182,6 +184,15 @@ def test_fusion_plan_and_mismatches(lib):
     assert call()[0] == 0
     st, msg = call(l1_shape=(Hkv, 32, D))            # default top-k 64 > 32 clusters
     assert st == PARAM_INVALID and "top-k" in msg
+    # the selection knobs are one-shot: a value serves the next phase 1 only, also when that call is rejected
+    assert lib.spfaSetTopK(16) == 0
+    assert call(l1_shape=(Hkv, 32, D))[0] == 0
+    st, msg = call(l1_shape=(Hkv, 32, D))
+    assert st == PARAM_INVALID and "top-k" in msg    # back to 64
+    assert lib.spfaSetTopK(16) == 0
+    assert call(ids_rows=3)[0] == PARAM_INVALID      # consumed by a call that fails for another reason
+    st, msg = call(l1_shape=(Hkv, 32, D))
+    assert st == PARAM_INVALID and "top-k" in msg
     st, msg = call(ids_rows=3)
     assert st == PARAM_INVALID and "block_ids" in msg
     st, msg = call(seq_dtype=I64)                    # total_seq_len is int32 in the reference (…Us2.h:1664)
@@ -190,3 +201,12 @@ def test_fusion_plan_and_mismatches(lib):
     assert st == PARAM_INVALID and "block_position" in msg
     st, msg = call(l1_shape=(4, C, D))
     assert st == PARAM_INVALID
+
+
+def test_device_lengths_are_disarmed_by_a_rejected_call(lib):
+    """spfaSetActualSeqLengthsDevice is consumed by the next attention phase 1 even if that call fails early."""
+    assert lib.spfaSetActualSeqLengthsDevice(c_void_p(0x5000), 1) == 0     # too few values for batch 3 ...
+    st, _, msg = attention(lib, bs=100)                                     # ... but the call fails before that check
+    assert st == PARAM_INVALID and "blockSize" in msg
+    st, _, msg = attention(lib)                                             # the next call reads its own (absent) host array
+    assert st == 0, msg

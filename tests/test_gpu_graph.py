@@ -10,8 +10,11 @@ import datagen
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("Hq,Hkv,B", [(8, 8, 3), (8, 2, 3), (32, 32, 40)])
-def test_prepared_launch_in_a_hip_graph(Hq, Hkv, B):
+@pytest.mark.parametrize("Hq,Hkv,B,persistent", [(8, 8, 3, True), (8, 2, 3, True), (32, 32, 40, True), (8, 2, 3, False),
+                                                 (32, 32, 40, False)])
+def test_prepared_launch_in_a_hip_graph(Hq, Hkv, B, persistent):
+    """persistent: the plan's workspace keeps its zeroed counters between launches (one kernel per launch after the
+    first); otherwise every launch, captured ones included, starts with the zeroing kernel."""
     import custom_ops
     import gpu_helpers as H
     D, C, topk, bs, max_page, kv_page_len = 128, 256, 8, 128, 40, 120
@@ -24,7 +27,7 @@ def test_prepared_launch_in_a_hip_graph(Hq, Hkv, B):
     plen = torch.empty((B, Hq, 8), dtype=torch.int32, device=H.DEV)
     pmax = torch.empty((B, 8), dtype=torch.int64, device=H.DEV)
     plan = custom_ops.PreparedFusion(qd, kd, vd, td, l1d, idsd, seqd, pos, plen, pmax, Hq, D ** -0.5, Hkv, bs, k=topk,
-                                     out_dtype=torch.float32)
+                                     out_dtype=torch.float32, persistent_workspace=persistent)
     plan.run()
     torch.cuda.synchronize()
     side = torch.cuda.Stream()
@@ -49,3 +52,47 @@ def test_prepared_launch_in_a_hip_graph(Hq, Hkv, B):
         assert float((got[0] - plan.out).abs().max()) <= 2e-6 * scale
         assert bool(torch.isfinite(got[0]).all()) and float(got[0].abs().max()) > 0
     plan.close()
+
+
+def test_one_shot_launch_with_host_lengths_can_be_captured():
+    """Per-batch actual_seq_lengths from the host travel as kernel arguments, so even a one-shot executor (consumed by
+    phase 2, which is all the capture sees) leaves nothing behind that a replay could find freed."""
+    import ctypes
+
+    import gpu_helpers as H
+    from custom_ops import _abi
+    B, Hq, Hkv, D, bs, P, n_blocks = 3, 8, 2, 128, 128, 12, 40
+    rng = datagen.rng_for(21)
+    q = H.dev(datagen.ref_rand_f16(rng, (B, Hq, D)))
+    k_np, v_np = datagen.kv_case(21, n_blocks, bs, Hkv, D, "BSH", dist="randn")
+    key, val = H.dev(k_np), H.dev(v_np)
+    table = H.dev(rng.integers(0, n_blocks, size=(B, 24)).astype(np.int32))
+    pos = H.dev(np.stack([np.stack([np.sort(rng.permutation(24)[:P]) for _ in range(Hkv)]) for _ in range(B)]).astype(np.int32))
+    lengths = [3 * bs + 5, P * bs, bs - 1]                       # not uniform: they go through the workspace
+    want = H.call_attention(q, key, val, table, pos, lengths, Hq, Hkv, D ** -0.5, bs, out_dtype=torch.float32)
+    torch.cuda.synchronize()
+
+    out = torch.zeros((B, Hq, D), dtype=torch.float32, device=H.DEV)
+    tens = [_abi.to_acl(t) for t in (q, table, pos, out)]
+    kl, vl = _abi.to_acl_list([key]), _abi.to_acl_list([val])
+    arr = _abi.to_int_array(lengths)
+    ws_size, ex = ctypes.c_uint64(0), _abi.T()
+    args = [tens[0], kl, vl, None, None, arr] + [None] * 7 + [tens[1], None, tens[2], Hq, D ** -0.5, b"BNSD", Hkv, bs, 1,
+                                                               tens[3]]
+    _abi.check(_abi.aclnnSparsePagedAttentionGetWorkspaceSize(*args, ctypes.byref(ws_size), ctypes.byref(ex)), "phase 1")
+    for d in tens:                                               # descriptors may die right after phase 1
+        _abi.aclDestroyTensor(d)
+    _abi.aclDestroyTensorList(kl); _abi.aclDestroyTensorList(vl); _abi.aclDestroyIntArray(arr)
+    ws = torch.empty(int(ws_size.value), dtype=torch.uint8, device=H.DEV)
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            _abi.check(_abi.aclnnSparsePagedAttention(ws.data_ptr(), int(ws_size.value), ex, _abi.current_stream(q.device)),
+                       "phase 2 under capture")                 # consumes the executor
+    for _ in range(2):
+        out.zero_()
+        ws.fill_(0xAB)                                           # the workspace is scratch between launches
+        graph.replay()
+        torch.cuda.synchronize()
+        assert float((out - want).abs().max()) <= 2e-6 * float(want.abs().max())

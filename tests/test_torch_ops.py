@@ -105,3 +105,91 @@ def test_dispatcher_passes_the_optional_operands():
     plain = custom_ops.sparse_paged_attention(q, key, val, e, e, act, e, e, e, sc, e, e, e, table, ei, pos, Hq, D ** -0.5,
                                               "BNSD", Hkv, bs, 1)
     assert not torch.equal(o1, plain)          # bias and mask took effect
+
+
+def test_meta_implementations_give_the_output_shapes():
+    """Shape-only implementations (the torch_npu fork registers the same, op_plugin/python/meta/
+    _meta_registrations.py:38-93): the ops can be traced without running a kernel."""
+    m = lambda shape, dt=torch.float16: torch.empty(shape, dtype=dt, device="meta")
+    B, Hq, Hkv, D, C = 4, 8, 2, 128, 256
+    q, l1 = m((B, Hq, D)), m((Hkv, C, D))
+    ids, table, seq = m((Hkv, 96), torch.int32), m((B + 2, 80), torch.int32), m((B - 1,), torch.int32)
+    assert torch.ops.myops.compute_cent(q, l1).shape == (B, Hq, 64)
+    pos, plen, pmax = torch.ops.myops.cent_select(q, l1, ids, table, seq)
+    assert pos.shape == (B - 1, Hq, 256) and plen.shape == (B - 1, Hq, 8) and pmax.shape == (B - 1, 8)
+    assert pmax.dtype == torch.int64 and pos.dtype == torch.int32
+    idx = m((B - 1, Hq, 64), torch.int32)
+    a, b, c = torch.ops.myops.select_position(ids, table, seq, idx)
+    assert a.shape == (B - 1, Hq, 256) and b.shape == (B - 1, Hq, 8) and c.shape == (B - 1, Hq, 80)
+    e, ei = m((0,)), m((0,), torch.int64)
+    kv = m((96, 128, Hkv, D))
+    out = torch.ops.myops.sparse_paged_attention(q, [kv], [kv], e, e, ei, e, e, e, e, e, e, e, table, ei, pos, Hq, 0.1,
+                                                 "BNSD", Hkv, 128, 1)
+    assert out.shape == q.shape and out.dtype == q.dtype
+    out = torch.ops.myops.sparse_paged_attention(q, [kv], [kv], e, e, ei, e, e, e, m((1,), torch.float32), e, e, e,
+                                                 table, ei, pos, Hq, 0.1, "BNSD", Hkv, 128, 1)
+    assert out.dtype == torch.int8
+    o, p2, m2 = torch.ops.myops.sparse_paged_fusion_attention(q, [kv], [kv], e, e, ei, e, e, e, e, e, e, e, table, ei, l1,
+                                                              ids, seq, pos, plen, pmax, Hq, 0.1, "BNSD", Hkv, 128, 1)
+    assert o.shape == q.shape and p2.shape == pos.shape and m2.shape == pmax.shape
+
+
+def _small_fused_case(dev, seed=5):
+    B, Hq, Hkv, D, C, bs, pages = 3, 8, 2, 128, 256, 128, 24
+    q, l1 = datagen.cent_case(seed, B, Hq, Hkv, D, C)
+    block_ids, table, seq = datagen.page_case(seed, Hkv, C, B * pages, B, pages, [pages * bs, 9 * bs + 3, 17 * bs],
+                                              aliasing=False)
+    k_np, v_np = datagen.kv_case(seed, B * pages, bs, Hkv, D, "BSH")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    return dict(B=B, Hq=Hq, Hkv=Hkv, D=D, C=C, bs=bs, np=(q, l1, block_ids, table, seq, k_np, v_np),
+                dev=tuple(map(t, (q, l1, block_ids, table, seq, k_np, v_np))))
+
+
+@pytest.mark.gpu
+def test_fused_op_traces_under_torch_compile():
+    """torch.compile(fullgraph=True) must get through the fused op without a graph break: it propagates shapes with the
+    meta implementation and calls the real one.  (backend "eager": the captured graph is run as it is.)"""
+    dev = "cuda:0"
+    c = _small_fused_case(dev)
+    q, l1, block_ids, table, seq, key, val = c["dev"]
+    B, Hq, Hkv, D, bs = c["B"], c["Hq"], c["Hkv"], c["D"], c["bs"]
+    e = torch.empty(0, dtype=torch.float16, device=dev)
+    ei = torch.empty(0, dtype=torch.int64, device=dev)
+
+    def layer(q, pos, plen, pmax):
+        out, pos2, pmax2 = torch.ops.myops.sparse_paged_fusion_attention(
+            q, [key], [val], e, e, ei, e, e, e, e, e, e, e, table, ei, l1, block_ids, seq, pos, plen, pmax, Hq,
+            D ** -0.5, "BNSD", Hkv, bs, 1)
+        return out.float() * 2.0, pmax2
+
+    bufs = lambda: (torch.empty((B, Hq, 256), dtype=torch.int32, device=dev),
+                    torch.empty((B, Hq, 8), dtype=torch.int32, device=dev),
+                    torch.empty((B, 8), dtype=torch.int64, device=dev))
+    want_bufs, got_bufs = bufs(), bufs()
+    want, want_max = layer(q, *want_bufs)
+    got, got_max = torch.compile(layer, fullgraph=True, backend="eager")(q, *got_bufs)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want) and torch.equal(got_max, want_max)
+    assert all(torch.equal(a, b) for a, b in zip(got_bufs, want_bufs))
+
+
+@pytest.mark.gpu
+def test_dispatch_defaults_reach_the_kernel_variant():
+    """torch.ops.myops.* take no keyword extras; set_dispatch_defaults selects k and the device kernel's sink/recent
+    pages and pageLen/8 cap (cent_select.cpp:350-362,410-414) for them.  Checked against the oracle."""
+    from oracle import ref
+    dev = "cuda:0"
+    c = _small_fused_case(dev, seed=8)
+    qn, l1n, idsn, tablen, seqn, _, _ = c["np"]
+    q, l1, block_ids, table, seq, _, _ = c["dev"]
+    before = custom_ops.set_dispatch_defaults(k=16, sink_recent=True, max_pages_cap=True)
+    try:
+        pos, plen, pmax = torch.ops.myops.cent_select(q, l1, block_ids, table, seq)
+    finally:
+        custom_ops.set_dispatch_defaults(**before)
+    wpos, wlen, wmax, _ = ref.cent_select(qn, l1n, idsn, tablen, seqn, k=16, sink_recent=True, max_pages_cap=True)
+    assert np.array_equal(pos.cpu().numpy(), wpos) and np.array_equal(plen.cpu().numpy(), wlen)
+    assert np.array_equal(pmax.cpu().numpy(), wmax)
+    plain = torch.ops.myops.cent_select(q, l1, block_ids, table, seq)        # defaults again: k = 64, oracle behaviour
+    w2 = ref.cent_select(qn, l1n, idsn, tablen, seqn, k=64)
+    assert np.array_equal(plain[0].cpu().numpy(), w2[0]) and np.array_equal(plain[1].cpu().numpy(), w2[1])

@@ -4,7 +4,11 @@
 FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts the 128-byte requests of 16 B/lane streaming reads as
 64 bytes, so it is doubled.  Usage: tools/make_traffic.py profiles/r01_pmc.json profiles/traffic.json"""
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_source_stamp  # noqa: E402  (sha256 of the kernel sources the counters were taken on)
 
 KEYS = {  # pmc.json prefix -> workload key of bench.py (workload_name)
     "c3": "B64_H32_KV32_D128_S32768_C2048_k32_f16",
@@ -26,6 +30,7 @@ def attn(entries, counter):
 def main(src, dst):
     d = json.load(open(src))
     out = {}
+    stamp = kernel_source_stamp()
     for pre, key in KEYS.items():
         f = attn(d.get(pre + "_fetch", []), "FETCH_SIZE")
         if f is None:
@@ -43,7 +48,8 @@ def main(src, dst):
                 raw[c] = e["mean"]
         out[key] = {"fetch_bytes_corrected": fetch, "raw": raw,
                     "kernel_mean_duration_ns_under_pmc": f["mean_duration_ns"], "write_bytes": write,
-                    "hbm_bytes_per_launch": fetch + write, "method": METHOD}
+                    "hbm_bytes_per_launch": fetch + write, "method": METHOD,
+                    "kernel_source_stamp": stamp}
     json.dump(out, open(dst, "w"), indent=1)
     for k, v in out.items():
         print(k, "%.3f GB" % (v["hbm_bytes_per_launch"] / 1e9))
