@@ -731,6 +731,10 @@ static void plan_workspace(aclOpExecutor* e) {
     const int n_cu = spfa::device_cu_count();
     long long cap = 0;   // resident workgroups of the kernel this plan selects (no device: 0, no split)
     e->device = current_device_or_none();
+    if (e->device >= 0 && p.mode == 1) {   // set-up time: the library-owned scratch of this device gets its address now
+        void* unused = nullptr;
+        if (spfa::static_scratch(&unused, nullptr) != hipSuccess) (void)hipGetLastError();
+    }
     p.grid_cap = 0;
     if (n_cu > 0 && items > 0 && spfa::launch_attention(p, nullptr, &cap) != hipSuccess) cap = 0;
     p.grid_cap = cap;   // phase 2 launches with this: no runtime queries on the launch path
@@ -995,6 +999,41 @@ aclnnStatus aclnnSparsePagedFusionAttention(void* workspace, uint64_t workspaceS
     if (err == hipSuccess) err = spfa::launch_attention(p, (hipStream_t)stream);
     if (executor->repeatable) executor->clean_ws = err == hipSuccess ? workspace : nullptr;
     return finish(executor, err, "sparse_paged_fusion_attention launch");
+}
+
+// Phase 2 of SparsePagedFusionAttention for callers that cannot allocate device memory: the workspace is a fixed array
+// inside the library's code object (one per GPU, 32 MiB) instead of a caller buffer.  Nothing is allocated or freed, on
+// the device or through any allocating runtime call.  The array keeps what the previous call left: the kernels leave
+// its counter area zeroed, and a zeroing kernel runs first whenever this launch needs a longer zeroed prefix than the
+// last one left (or the last enqueue failed).  Calls that overlap on one GPU share the array and race.
+aclnnStatus aclnnSparsePagedFusionAttentionNoAlloc(aclOpExecutor* executor, const aclrtStream stream) {
+    REQUIRE_PTR(executor, "executor");
+    REQUIRE(executor->op == kOpFusion, "executor was not created by aclnnSparsePagedFusionAttentionGetWorkspaceSize");
+    auto drop = [&]() { if (!executor->repeatable) delete executor; };
+    if (executor->ws_bytes > spfa::kStaticScratchBytes) {
+        const unsigned long long need = executor->ws_bytes;
+        drop();
+        return fail(ACLNN_ERR_PARAM_INVALID,
+                    "this launch needs %llu bytes of workspace, the built-in scratch holds %llu: plan it with "
+                    "spfaSetTailSharing(0) (and spfaSetMaxSplit(1) for small batches), or pass a workspace to "
+                    "aclnnSparsePagedFusionAttention", need, (unsigned long long)spfa::kStaticScratchBytes);
+    }
+    {
+        const aclnnStatus ds = check_device(executor);
+        if (ds != ACLNN_SUCCESS) { drop(); return ds; }
+    }
+    void* scratch_ptr = nullptr;
+    int dev = -1;
+    hipError_t err = spfa::static_scratch(&scratch_ptr, &dev);
+    if (err != hipSuccess) { drop(); return hip_fail(err, "address of the built-in scratch"); }
+    // zeroed prefix the previous launch on this device left (its own counter area), per device
+    static uint64_t zero_prefix[64];
+    spfa::AttnParams p = executor->attn;
+    const uint64_t had = __atomic_load_n(&zero_prefix[dev], __ATOMIC_ACQUIRE);
+    err = bind_workspace(executor, p, scratch_ptr, (hipStream_t)stream, executor->ws_zero_bytes > had);
+    if (err == hipSuccess) err = spfa::launch_attention(p, (hipStream_t)stream);
+    __atomic_store_n(&zero_prefix[dev], err == hipSuccess ? executor->ws_zero_bytes : 0, __ATOMIC_RELEASE);
+    return finish(executor, err, "sparse_paged_fusion_attention launch (built-in scratch)");
 }
 
 }  // extern "C"

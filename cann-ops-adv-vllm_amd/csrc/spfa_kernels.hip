@@ -237,6 +237,28 @@ hipError_t launch_store_lengths(long long* dst, const long long* host, int n, hi
     return hipSuccess;
 }
 
+// Scratch for the entry point that must not allocate: every GPU this library runs on holds one copy of this array from
+// the moment the code object is loaded until the process ends.  In host code the symbol is only a handle; the device
+// address is looked up once per device (with that device current) and kept.
+static __device__ __align__(256) __attribute__((used)) unsigned char scratch[kStaticScratchBytes];
+hipError_t static_scratch(void** ptr, int* device) {
+    static void* addr[kMaxDevices];
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= kMaxDevices) return hipErrorInvalidDevice;
+    void* a = __atomic_load_n(&addr[dev], __ATOMIC_ACQUIRE);
+    if (a == nullptr) {
+        e = hipGetSymbolAddress(&a, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (a == nullptr) return hipErrorInvalidSymbol;
+        __atomic_store_n(&addr[dev], a, __ATOMIC_RELEASE);
+    }
+    *ptr = a;
+    if (device) *device = dev;
+    return hipSuccess;
+}
+
 int device_cu_count() {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;

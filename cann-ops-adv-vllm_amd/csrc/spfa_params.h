@@ -140,6 +140,10 @@ hipError_t launch_zero(void* a, size_t a_bytes, void* b, size_t b_bytes, hipStre
 // Enqueue dst[0..n) = host[0..n): the values travel as kernel arguments (copied when the launch is enqueued or captured),
 // so the host array may die as soon as the call returns and nothing is allocated or waited for.
 hipError_t launch_store_lengths(long long* dst, const long long* host, int n, hipStream_t s);
+// Library-owned scratch of the current device (a file-scope __device__ array, zero when the library is loaded) for the
+// entry point that takes no workspace: its device address and size.  Looked up once per device.
+constexpr size_t kStaticScratchBytes = (size_t)32 << 20;
+hipError_t static_scratch(void** ptr, int* device);
 // Compute units of the current device (0 when no device can be queried).
 int device_cu_count();
 // Number of q heads of a group one pass over the K/V pages serves, and whether that pass runs on the MFMA streamer

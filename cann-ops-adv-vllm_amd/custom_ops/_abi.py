@@ -78,6 +78,7 @@ aclnnSparsePagedAttention = _sig("aclnnSparsePagedAttention", c_int, _EXEC)
 aclnnSparsePagedFusionAttentionGetWorkspaceSize = _sig(
     "aclnnSparsePagedFusionAttentionGetWorkspaceSize", c_int, [T] * 18 + _ATTRS + [T] * 4 + _WS)
 aclnnSparsePagedFusionAttention = _sig("aclnnSparsePagedFusionAttention", c_int, _EXEC)
+aclnnSparsePagedFusionAttentionNoAlloc = _sig("aclnnSparsePagedFusionAttentionNoAlloc", c_int, [T, c_void_p])
 
 
 class AclError(RuntimeError):

@@ -32,6 +32,17 @@ SPFA_API aclnnStatus aclnnSparsePagedFusionAttentionGetWorkspaceSize(
     aclOpExecutor** executor);
 SPFA_API aclnnStatus aclnnSparsePagedFusionAttention(void* workspace, uint64_t workspaceSize,
                                                      aclOpExecutor* executor, const aclrtStream stream);
+/*
+ * No counterpart in the reference.  For callers that cannot allocate device memory: code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc.  Phase 2 of the fused op without a workspace argument: the
+ * counters, boards and partial states that aclnnSparsePagedFusionAttention keeps in the caller's workspace live in
+ * a fixed 32 MiB array inside the library (one copy per GPU, held until the process ends).  The executor comes from
+ * aclnnSparsePagedFusionAttentionGetWorkspaceSize as usual (inputs and outputs are bound there); a plan whose
+ * reported workspace exceeds 32 MiB is rejected with ACLNN_ERR_PARAM_INVALID and a text that says so.  The call
+ * allocates and frees nothing and enqueues on `stream` only.  All calls on one GPU share the array: calls that
+ * overlap on one GPU (two streams, two threads) race; calls ordered on one stream are safe.
+ */
+SPFA_API aclnnStatus aclnnSparsePagedFusionAttentionNoAlloc(aclOpExecutor* executor, const aclrtStream stream);
 #ifdef __cplusplus
 }
 #endif
