@@ -693,7 +693,7 @@ static size_t carve_lds(spfa::AttnParams& p, size_t nq) {
     p.off_qst = (int)off;
     if (!mfma) off += align16((size_t)2 * nq * p.D * 4);                   // pre-scaled q rows (VALU streamer)
     p.off_hdr = (int)off;
-    off += 2 * 48 + 16;                                                    // two item headers + 4 workgroup words
+    off += 2 * 48 + 16 + 64;                                               // two item headers + 4 workgroup words + 16 pipeline words
     p.off_vst = (int)off;
     if (mfma) off += sw * 32 * (p.D * 2 + 32);                             // V tile images of the streamer waves
     p.off_stage = (int)off;
@@ -764,6 +764,7 @@ static void plan_workspace(aclOpExecutor* e) {
     const bool mfma = spfa::attention_uses_mfma(p.rows_per_pass, p.kv_dtype, p.D);
     const bool worth = items >= 6ll * n_cu || (items > n_cu && (p.max_entries >= 512 || mfma));
     p.tail_on = (g_tail_sharing && p.n_split == 1 && n_cu > 0 && (worth || g_tail_sharing == 2)) ? 1 : 0;
+    p.dyn_pages = g_tail_sharing ? 1 : 0;   // spfaSetTailSharing(0) asks for a reproducible summation order
     const uint64_t n_boards = p.tail_on ? (uint64_t)(cap > 0 ? cap : 2ll * n_cu) : 0;   // one per resident workgroup
     const uint64_t state_bytes = (uint64_t)p.rows_per_pass * (p.D + 2) * 4;
     p.tail_chunks = p.rows_per_pass <= 4 ? 32 : 16;   // one state per chunk + the owner's: keep the wide ones fewer

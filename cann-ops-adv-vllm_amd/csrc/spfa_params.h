@@ -110,6 +110,9 @@ struct AttnParams {
     // works on stay the same (centroids in its L2); 1: every claim starts one class further, which mixes heads whose
     // page lists are systematically longer or shorter over all XCDs
     int class_step;
+    // 1: the streamer waves of a workgroup claim the pages of an item one by one from a counter in LDS (whoever is
+    // free takes the next page); 0: wave w takes pages w, w + 4, ... which makes attention_out bit-reproducible
+    int dyn_pages;
     // page-list split for small batches: n_split workgroups per item (1: off)
     int n_split;
     // sharing of every workgroup's last item (n_split == 1 only): boards and their data areas in the workspace
