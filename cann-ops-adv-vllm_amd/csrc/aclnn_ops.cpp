@@ -13,6 +13,7 @@
 #include <string>
 #include <vector>
 
+#include "../../include/aclnn_assign_block_ids.h"
 #include "../../include/aclnn_cent_select.h"
 #include "../../include/aclnn_compute_cent.h"
 #include "../../include/aclnn_select_position.h"
@@ -29,7 +30,7 @@ struct aclTensor {
 struct aclTensorList { std::vector<aclTensor*> items; };
 struct aclIntArray { std::vector<int64_t> v; };
 
-enum OpKind { kOpComputeCent, kOpSelectPosition, kOpCentSelect, kOpAttention, kOpFusion };
+enum OpKind { kOpComputeCent, kOpSelectPosition, kOpCentSelect, kOpAttention, kOpFusion, kOpAssign };
 
 struct aclOpExecutor {
     OpKind op;
@@ -37,6 +38,7 @@ struct aclOpExecutor {
     spfa::CentParams cent{};
     spfa::SelectParams sel{};
     spfa::AttnParams attn{};
+    spfa::AssignParams assign{};
     std::vector<long long> act_seq;   // host copy of actualSeqLengths, expanded to B values
     // workspace layout of the two attention ops: [work counters | split arrival counters] (zeroed per launch),
     // split states, per-batch actualSeqLengths
@@ -697,7 +699,7 @@ static size_t carve_lds(spfa::AttnParams& p, size_t nq) {
     p.off_vst = (int)off;
     if (mfma) off += sw * 32 * (p.D * 2 + 32);                             // V tile images of the streamer waves
     p.off_stage = (int)off;
-    if (p.mode == 1) off += (size_t)spfa::attention_stage_bytes(mfma, p.D);   // centroid tiles of the scoring waves
+    if (p.mode == 1) off += (size_t)spfa::attention_stage_bytes(mfma, p.kv_dtype, p.D);   // centroid tiles of the scoring waves
     return off;
 }
 
@@ -1000,6 +1002,101 @@ aclnnStatus aclnnSparsePagedFusionAttention(void* workspace, uint64_t workspaceS
     if (err == hipSuccess) err = spfa::launch_attention(p, (hipStream_t)stream);
     if (executor->repeatable) executor->clean_ws = err == hipSuccess ? workspace : nullptr;
     return finish(executor, err, "sparse_paged_fusion_attention launch");
+}
+
+// ------------------------------------------------------------------------------------------------
+// AssignBlockIds (no counterpart in the reference: the producer of block_ids)
+// ------------------------------------------------------------------------------------------------
+aclnnStatus aclnnAssignBlockIdsGetWorkspaceSize(const aclTensorList* key, const aclTensor* blockTable,
+                                                const aclTensor* seqLen, const aclTensor* firstNewPage,
+                                                const aclTensor* l1Cent, const aclTensor* antiquantScale,
+                                                const aclTensor* antiquantOffset, int64_t blockSize, int64_t maxNewPages,
+                                                const aclTensor* blockIdsInout, uint64_t* workspaceSize,
+                                                aclOpExecutor** executor) {
+    REQUIRE_PTR(workspaceSize, "workspaceSize");
+    REQUIRE_PTR(executor, "executor");
+    REQUIRE_PTR(l1Cent, "l1_cent");
+    REQUIRE(l1Cent->dtype == ACL_FLOAT16 || l1Cent->dtype == ACL_BF16, "l1_cent must be float16 or bfloat16");
+    REQUIRE(l1Cent->dims.size() == 3 && is_contiguous(l1Cent) && l1Cent->data, "l1_cent must be a contiguous [Hkv, C, D] tensor");
+    const int Hkv = (int)l1Cent->dims[0], C = (int)l1Cent->dims[1], D = (int)l1Cent->dims[2];
+    REQUIRE(Hkv > 0 && C > 0 && C <= 16384, "l1_cent: %d heads, %d clusters (1 .. 16384)", Hkv, C);
+    REQUIRE(D == 32 || D == 64 || D == 128 || D == 256 || D == 512, "head dim %d: must be 32, 64, 128, 256 or 512", D);
+    int B = 0, kv_page_len = 0, max_page = 0;
+    CHECK(check_page_tables(blockIdsInout, blockTable, seqLen, Hkv, &B, &kv_page_len, &max_page));
+    CHECK(check_tensor(firstNewPage, "first_new_page", 1, ACL_INT32));
+    REQUIRE(firstNewPage->dims[0] >= B, "first_new_page has %lld values < batch %d", (long long)firstNewPage->dims[0], B);
+    REQUIRE(key && key->items.size() == 1, "key must be a one-tensor list holding the paged K cache");
+    const aclTensor* kc = key->items[0];
+    REQUIRE(is_contiguous(kc) && kc->data, "key cache must be contiguous device memory");
+    const bool quant = kc->dtype == ACL_INT8;
+    REQUIRE(quant || kc->dtype == l1Cent->dtype, "key cache dtype must equal l1_cent's dtype or be int8");
+    const int es = quant ? 1 : 2;
+    REQUIRE(blockSize > 0 && blockSize <= 512, "blockSize %lld out of (0, 512]", (long long)blockSize);
+    const int bs = (int)blockSize;
+    const auto& kd = kc->dims;
+    bool bsh;
+    if (kd.size() == 3 && kd[1] == bs && kd[2] == (int64_t)Hkv * D) bsh = true;
+    else if (kd.size() == 4 && kd[1] == bs && kd[2] == Hkv && kd[3] == D) bsh = true;
+    else if (kd.size() == 4 && kd[1] == Hkv && kd[2] == bs && kd[3] == D) bsh = false;
+    else return fail(ACLNN_ERR_PARAM_INVALID, "key cache must be [blocks,bs,Hkv*D], [blocks,bs,Hkv,D] or [blocks,Hkv,bs,D]");
+    REQUIRE(kd[0] > 0 && kd[0] <= 0x7fffffff, "key cache has no blocks");
+    const int lpt = D * es / 16;
+    REQUIRE(lpt >= 4 && lpt <= 64, "head dim %d with %d-byte elements is not supported (row bytes 64 .. 1024)", D, es);
+    aclOpExecutor* e = new aclOpExecutor();
+    e->op = kOpAssign;
+    spfa::AssignParams& p = e->assign;
+    auto bail = [&](aclnnStatus s) { delete e; return s; };
+    if (quant) {
+        if (absent(antiquantScale)) return bail(fail(ACLNN_ERR_PARAM_INVALID, "int8 key cache needs antiquantScale"));
+        const bool per_tensor = antiquantScale->dims.size() == 1 && antiquantScale->dims[0] == 2;
+        const long long want = per_tensor ? 2 : 2ll * Hkv * D;
+        if (antiquantScale->dtype != l1Cent->dtype || numel(antiquantScale) != want || !is_contiguous(antiquantScale))
+            return bail(fail(ACLNN_ERR_PARAM_INVALID, "antiquantScale must be [2, Hkv, D] or [2] in l1_cent's dtype"));
+        if (!absent(antiquantOffset) && (antiquantOffset->dtype != l1Cent->dtype || numel(antiquantOffset) != want ||
+                                         !is_contiguous(antiquantOffset)))
+            return bail(fail(ACLNN_ERR_PARAM_INVALID, "antiquantOffset must have antiquantScale's shape and dtype"));
+        p.antiq_per_tensor = per_tensor ? 1 : 0;
+        p.antiq_scale = data_ptr(antiquantScale);
+        p.antiq_offset = absent(antiquantOffset) ? nullptr : data_ptr(antiquantOffset);
+    } else if (!absent(antiquantScale) || !absent(antiquantOffset)) {
+        return bail(fail(ACLNN_ERR_PARAM_INVALID, "antiquant parameters given but the key cache is not int8"));
+    }
+    p.kcache = data_ptr(kc);
+    if (bsh) {
+        p.blk_stride = (long long)bs * Hkv * D * es; p.tok_stride = (long long)Hkv * D * es; p.head_stride = (long long)D * es;
+    } else {
+        p.blk_stride = (long long)Hkv * bs * D * es; p.head_stride = (long long)bs * D * es; p.tok_stride = (long long)D * es;
+    }
+    p.kv_dtype = to_dtype(kc->dtype);
+    p.n_blocks = (int)kd[0];
+    p.cent = data_ptr(l1Cent);
+    p.qk_dtype = to_dtype(l1Cent->dtype);
+    p.block_table = (const int32_t*)data_ptr(blockTable);
+    p.seq_len = (const int32_t*)data_ptr(seqLen);
+    p.first_new = (const int32_t*)data_ptr(firstNewPage);
+    p.B = B; p.Hkv = Hkv; p.D = D; p.C = C; p.Cp = round_up(C, 128); p.block_size = bs; p.max_page = max_page;
+    p.max_new = (maxNewPages <= 0 || maxNewPages > max_page) ? max_page : (int)maxNewPages;
+    p.kv_page_len = kv_page_len;
+    p.block_ids = (int32_t*)data_ptr(blockIdsInout);
+    int rows = 16;   // as many rows per centroid pass as the keys leave room for
+    while (rows > 1 && spfa::assign_lds_bytes(rows, p.Cp, D) > 150 * 1024) --rows;
+    p.rows_per_pass = rows;
+    p.lds_bytes = spfa::assign_lds_bytes(rows, p.Cp, D);
+    if (p.lds_bytes > kMaxLds) return bail(fail(ACLNN_ERR_PARAM_INVALID, "%d clusters need %zu bytes of LDS (> %zu)", C, p.lds_bytes, kMaxLds));
+    e->device = current_device_or_none();
+    *workspaceSize = 0;
+    *executor = e;
+    return ACLNN_SUCCESS;
+}
+
+aclnnStatus aclnnAssignBlockIds(void*, uint64_t, aclOpExecutor* executor, aclrtStream stream) {
+    REQUIRE_PTR(executor, "executor");
+    REQUIRE(executor->op == kOpAssign, "executor was not created by aclnnAssignBlockIdsGetWorkspaceSize");
+    {
+        const aclnnStatus ds = check_device(executor);
+        if (ds != ACLNN_SUCCESS) { if (!executor->repeatable) delete executor; return ds; }
+    }
+    return finish(executor, spfa::launch_assign(executor->assign, (hipStream_t)stream), "assign_block_ids launch");
 }
 
 // Phase 2 of SparsePagedFusionAttention for callers that cannot allocate device memory: the workspace is a fixed array

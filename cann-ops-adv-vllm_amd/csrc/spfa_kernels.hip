@@ -108,6 +108,7 @@ __device__ __forceinline__ float load_qk_elem(const void* p, int dtype, long lon
 #include "spfa_stream_valu.inc"
 #include "spfa_stream_mfma.inc"
 #include "spfa_attn_kernel.inc"
+#include "spfa_assign.inc"
 
 constexpr int kMaxDevices = 64;
 // Raise a kernel's dynamic-LDS limit on the current device when `bytes` exceeds what was set before (the limit is a
@@ -273,8 +274,8 @@ bool attention_uses_mfma(int rows_per_pass, int kv_dtype, int D) {
 }
 
 int attention_stream_waves(bool mfma, int kv_dtype) { return stream_waves(mfma, kv_dtype == kI8); }
-int attention_stage_bytes(bool mfma, int D) {
-    return (mfma ? sel_waves(true) : stream_waves(false, false) + sel_waves(false)) * score_stage_bytes(D);
+int attention_stage_bytes(bool mfma, int kv_dtype, int D) {
+    return (mfma ? sel_waves(true) : stream_waves(false, kv_dtype == kI8) + sel_waves(false)) * score_stage_bytes(D);
 }
 int cent_stage_bytes(int D) { return 4 * score_stage_bytes(D); }
 
@@ -335,6 +336,20 @@ static hipError_t launch_cent(const CentParams& p, int mode, hipStream_t s) {
 }
 hipError_t launch_compute_cent(const CentParams& p, hipStream_t s) { return launch_cent(p, 0, s); }
 hipError_t launch_cent_select(const CentParams& p, hipStream_t s) { return launch_cent(p, 1, s); }
+
+size_t assign_lds_bytes(int rows_per_pass, int Cp, int D) {
+    return (size_t)rows_per_pass * Cp * 4 + (size_t)16 * D * 2 + 16 * sizeof(AssignSlot) + 16 + (size_t)cent_stage_bytes(D);
+}
+hipError_t launch_assign(const AssignParams& p, hipStream_t s) {
+    const long long groups = ((long long)p.B * p.max_new + p.rows_per_pass - 1) / p.rows_per_pass;
+    if (groups <= 0 || p.Hkv <= 0) return hipSuccess;
+    if (groups * p.Hkv > 0x7fffffffll) return hipErrorInvalidConfiguration;
+    static int lds_limit[kMaxDevices];
+    const hipError_t le = ensure_lds_limit((const void*)assign_kernel, lds_limit, p.lds_bytes);
+    if (le != hipSuccess) return le;
+    hipLaunchKernelGGL(assign_kernel, dim3((unsigned)(groups * p.Hkv)), dim3(kThreads), p.lds_bytes, s, p);
+    return hipGetLastError();
+}
 
 hipError_t launch_select_position(const SelectParams& p, hipStream_t s) {
     const long long rows = (long long)p.B * p.Hq;

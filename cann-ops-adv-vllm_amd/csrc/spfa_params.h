@@ -50,6 +50,27 @@ struct SelectParams {
     int32_t* block_table_gather;   // [B, Hq, max_page]
 };
 
+// AssignBlockIds: cluster ids of newly filled KV pages.  One workgroup per (kv head, group of rows_per_pass new pages).
+struct AssignParams {
+    const void* kcache;        // BSH [blocks, bs, Hkv, D] | BNSD [blocks, Hkv, bs, D]
+    long long blk_stride, tok_stride, head_stride;   // bytes
+    int kv_dtype, n_blocks;
+    const void* cent;          // [Hkv, C, D] f16 | bf16
+    int qk_dtype;              // dtype of the centroids (the page means are rounded to it)
+    const void* antiq_scale;   // int8 K: [2, Hkv*D] or [2] in the centroid dtype (key parameters first), else null
+    const void* antiq_offset;  // same shape, or null
+    int antiq_per_tensor;
+    const int32_t* block_table;// [>=B, max_page]
+    const int32_t* seq_len;    // [B] tokens in the sequence
+    const int32_t* first_new;  // [B] first logical page without a cluster id yet
+    int B, Hkv, D, C, Cp, block_size, max_page;
+    int max_new;               // most new pages per sequence one call looks at
+    int rows_per_pass;         // new pages scored per centroid pass (<= 16; LDS budget of the keys)
+    int kv_page_len;
+    int32_t* block_ids;        // [Hkv, kv_page_len] in/out
+    size_t lds_bytes;
+};
+
 // SparsePagedAttention (mode 0) and SparsePagedFusionAttention (mode 1).
 struct AttnParams {
     int mode;                  // 0: page lists given (block_position), 1: fused cent-select first
@@ -136,6 +157,9 @@ struct AttnParams {
 hipError_t launch_compute_cent(const CentParams& p, hipStream_t s);
 hipError_t launch_cent_select(const CentParams& p, hipStream_t s);
 hipError_t launch_select_position(const SelectParams& p, hipStream_t s);
+hipError_t launch_assign(const AssignParams& p, hipStream_t s);
+// LDS of the assign kernel for rows_per_pass rows: keys, the A tile, the slot list, the centroid tiles of its 4 waves.
+size_t assign_lds_bytes(int rows_per_pass, int Cp, int D);
 // cap_out != nullptr: launch nothing, report how many workgroups of the kernel that would run can be resident.
 hipError_t launch_attention(const AttnParams& p, hipStream_t s, long long* cap_out = nullptr);
 // Enqueue the zeroing of up to two 8-byte aligned ranges (either may be null / empty) as one small kernel.
@@ -157,7 +181,7 @@ bool attention_uses_mfma(int rows_per_pass, int kv_dtype, int D);
 int attention_stream_waves(bool mfma, int kv_dtype);
 // LDS tiles through which the centroid pass turns memory order into matrix-core operand order: bytes at off_stage of
 // the attention kernels, and at the end of the dynamic LDS of the cent kernels.
-int attention_stage_bytes(bool mfma, int D);
+int attention_stage_bytes(bool mfma, int kv_dtype, int D);
 int cent_stage_bytes(int D);
 
 }  // namespace spfa

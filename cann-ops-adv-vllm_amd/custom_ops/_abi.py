@@ -78,6 +78,9 @@ aclnnSparsePagedAttention = _sig("aclnnSparsePagedAttention", c_int, _EXEC)
 aclnnSparsePagedFusionAttentionGetWorkspaceSize = _sig(
     "aclnnSparsePagedFusionAttentionGetWorkspaceSize", c_int, [T] * 18 + _ATTRS + [T] * 4 + _WS)
 aclnnSparsePagedFusionAttention = _sig("aclnnSparsePagedFusionAttention", c_int, _EXEC)
+aclnnAssignBlockIdsGetWorkspaceSize = _sig("aclnnAssignBlockIdsGetWorkspaceSize", c_int,
+                                           [T] * 7 + [c_int64, c_int64, T] + _WS)
+aclnnAssignBlockIds = _sig("aclnnAssignBlockIds", c_int, _EXEC)
 aclnnSparsePagedFusionAttentionNoAlloc = _sig("aclnnSparsePagedFusionAttentionNoAlloc", c_int, [T, c_void_p])
 
 

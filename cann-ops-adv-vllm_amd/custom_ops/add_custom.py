@@ -210,6 +210,30 @@ def sparse_paged_fusion_attention(query: torch.Tensor, key: torch.Tensor, value:
     return out, block_position, max_page_position_length
 
 
+def assign_block_ids(key: torch.Tensor, block_table: torch.Tensor, seq_len: torch.Tensor, l1_cent: torch.Tensor,
+                     block_ids: torch.Tensor, first_new_page: torch.Tensor, *, block_size: int = 128,
+                     max_new_pages: int = 0, antiquant_scale: Optional[torch.Tensor] = None,
+                     antiquant_offset: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Cluster ids for newly filled KV pages, written into block_ids [Hkv, kvPageLen] in place (returned).
+
+    Not in the reference, which only consumes block_ids (README.md:33): for every sequence b and logical page i
+    with first_new_page[b] <= i < ceil(seq_len[b] / block_size) (at most max_new_pages per sequence; 0 = all) and every
+    kv head, the mean K row of the page (rounded to l1_cent's dtype) is scored against the head's centroids like a
+    query row and the page gets the best cluster's id (ties: smallest id).  A decode loop calls this when a page
+    fills up and advances first_new_page itself."""
+    _abi.require_gpu(key, block_table, seq_len, l1_cent, block_ids, first_new_page)
+    dev = key.device
+    kl = _abi.to_acl_list([key])
+    descs = [_abi.to_acl(t) for t in (block_table, seq_len, first_new_page, l1_cent, antiquant_scale, antiquant_offset)]
+    ids_d = _abi.to_acl(block_ids)
+    try:
+        _abi.run(_abi.aclnnAssignBlockIdsGetWorkspaceSize, _abi.aclnnAssignBlockIds,
+                 [kl] + descs + [int(block_size), int(max_new_pages), ids_d], dev, "aclnnAssignBlockIds")
+    finally:
+        _destroy(descs + [ids_d], [kl])
+    return block_ids
+
+
 class PreparedFusion:
     """Plan once, launch many: keeps the executor of sparse_paged_fusion_attention alive
     (aclSetAclOpExecutorRepeatable, the pattern of extension/csrc/add_custom.cpp:847,886-895) so a

@@ -373,3 +373,68 @@ def sparse_paged_fusion_attention(q, key_cache, value_cache, block_table, l1_cen
                                  pse_shift=pse_shift, atten_mask=atten_mask, quant_scale2=quant_scale2,
                                  quant_offset2=quant_offset2)
     return out, pos, len8, max8
+
+
+# --------------------------------------------------------------------------- #
+# assign_block_ids: cluster ids of newly filled pages.  The reference has NO producer of
+# block_ids (README.md:33 only describes the tensor), so there is nothing to pin this
+# against: "parity unpinned".  The definition below is the one the HIP kernel implements.
+# --------------------------------------------------------------------------- #
+def page_means(key_cache, block_table, seq_len, first_new_page, num_kv_heads: int, head_dim: int,
+               block_size: int = 128, kv_layout: str = "BSH", max_new_pages: int = 0,
+               antiquant_scale=None, antiquant_offset=None, dt: str = "f16"):
+    """[(b, page, phys, mean[Hkv, D] rounded to dt)] for every new page, in (b, page) order.
+
+    mean = fp32 sum over the page's live tokens times fp32 (1 / tokens); int8 K:
+    (mean + offset_k) * scale_k per channel (key parameters = index 0, …Us2.h:2035-2043)."""
+    bt = np.asarray(block_table)
+    seq_len = np.asarray(seq_len)
+    first = np.asarray(first_new_page)
+    Hkv, D = num_kv_heads, head_dim
+    max_page = bt.shape[1]
+    max_new = max_page if max_new_pages <= 0 else min(int(max_new_pages), max_page)
+    n_blocks = key_cache.shape[0]
+    rnd = round_to_bf16 if dt == "bf16" else round_to_f16
+    quant = antiquant_scale is not None
+    if quant:
+        def _params(t):
+            t = np.asarray(t, dtype=np.float32)
+            return np.broadcast_to(t.reshape(2, 1, 1), (2, Hkv, D)) if t.size == 2 else t.reshape(2, Hkv, D)
+        a_s = _params(antiquant_scale)
+        a_o = _params(antiquant_offset) if antiquant_offset is not None else None
+    out = []
+    for b in range(seq_len.shape[0]):
+        page_len = max(0, min((int(seq_len[b]) + block_size - 1) // block_size, max_page))
+        f0 = max(0, int(first[b]))
+        for page in range(f0, min(page_len, f0 + max_new)):
+            phys = int(np.clip(bt[b, page], 0, n_blocks - 1))
+            valid = min(block_size, int(seq_len[b]) - page * block_size)
+            m = np.zeros((Hkv, D), np.float32)
+            for n2 in range(Hkv):
+                rows = _kv_rows(key_cache, phys, n2, kv_layout, Hkv, D)[:valid].astype(np.float64)
+                ssum = rows.sum(axis=0).astype(np.float32)
+                m[n2] = ssum * (np.float32(1.0) / np.float32(valid))
+                if quant:
+                    if a_o is not None:
+                        m[n2] = m[n2] + a_o[0, n2]
+                    m[n2] = m[n2] * a_s[0, n2]
+            out.append((b, page, phys, rnd(m)))
+    return out
+
+
+def assign_block_ids(key_cache, block_table, seq_len, first_new_page, l1_cent, block_ids,
+                     block_size: int = 128, kv_layout: str = "BSH", max_new_pages: int = 0,
+                     antiquant_scale=None, antiquant_offset=None, dt: str = "f16"):
+    """block_ids[n, phys] = argmax_c mean'(page, n) . l1_cent[n, c, :] for every new page (ties: smallest c).
+    Returns (new block_ids, scores) where scores[(b, page)] = float64 [Hkv, C] of that page."""
+    l1 = np.asarray(l1_cent, dtype=np.float64)
+    Hkv, C, D = l1.shape
+    ids = np.array(block_ids, copy=True)
+    scores = {}
+    for b, page, phys, m in page_means(key_cache, block_table, seq_len, first_new_page, Hkv, D, block_size,
+                                       kv_layout, max_new_pages, antiquant_scale, antiquant_offset, dt):
+        sc = np.einsum("nd,ncd->nc", m.astype(np.float64), l1)
+        scores[(b, page)] = sc
+        if phys < ids.shape[1]:
+            ids[:, phys] = np.argmax(sc, axis=1).astype(np.int32)     # first maximum = smallest id
+    return ids, scores

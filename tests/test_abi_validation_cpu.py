@@ -30,6 +30,7 @@ def lib():
     L.aclnnSparsePagedAttentionGetWorkspaceSize.argtypes = [T] * 16 + attrs + [T, POINTER(c_uint64), POINTER(T)]
     L.aclnnSparsePagedFusionAttentionGetWorkspaceSize.argtypes = [T] * 18 + attrs + [T] * 4 + [POINTER(c_uint64), POINTER(T)]
     L.aclnnCentSelectGetWorkspaceSize.argtypes = [T] * 9 + [POINTER(c_uint64), POINTER(T)]
+    L.aclnnAssignBlockIdsGetWorkspaceSize.argtypes = [T] * 7 + [c_int64, c_int64, T, POINTER(c_uint64), POINTER(T)]
     L.spfaSetTopK.argtypes = [c_int64]
     L.spfaSetActualSeqLengthsDevice.argtypes = [c_void_p, c_int64]
     return L
@@ -210,3 +211,37 @@ def test_device_lengths_are_disarmed_by_a_rejected_call(lib):
     assert st == PARAM_INVALID and "blockSize" in msg
     st, _, msg = attention(lib)                                             # the next call reads its own (absent) host array
     assert st == 0, msg
+
+
+def test_assign_block_ids_plan_and_mismatches(lib):
+    B, Hkv, D, C, bs = 4, 2, 128, 512, 128
+
+    def call(kv_shape=(64, bs, Hkv, D), kv_dtype=F16, first_dtype=I32, first_n=B, antiq=None, ids_rows=Hkv, l1_dtype=F16,
+             block_size=bs):
+        ws, ex = c_uint64(0), c_void_p()
+        st = lib.aclnnAssignBlockIdsGetWorkspaceSize(
+            tlist(lib, tensor(lib, kv_shape, kv_dtype)), tensor(lib, (B, 16), I32), tensor(lib, (B,), I32),
+            tensor(lib, (first_n,), first_dtype), tensor(lib, (Hkv, C, D), l1_dtype), antiq, None, block_size, 0,
+            tensor(lib, (ids_rows, 64), I32), ctypes.byref(ws), ctypes.byref(ex))
+        if st == 0:
+            lib.aclDestroyAclOpExecutor(ex)
+        return st, ws.value, (lib.aclGetRecentErrMsg() or b"").decode()
+
+    st, ws, msg = call()
+    assert st == 0 and ws == 0, msg
+    assert call(kv_shape=(64, Hkv, bs, D))[0] == 0                     # [blocks, Hkv, bs, D]
+    assert call(kv_shape=(64, bs, Hkv * D))[0] == 0
+    assert call(kv_dtype=I8, antiq=tensor(lib, (2, Hkv, D), F16))[0] == 0
+    for kw, fragment in [
+        (dict(kv_dtype=I8), "needs antiquantScale"),
+        (dict(antiq=tensor(lib, (2, Hkv, D), F16)), "not int8"),
+        (dict(kv_dtype=BF16), "key cache dtype"),
+        (dict(kv_shape=(64, bs, Hkv, 64)), "key cache must be"),
+        (dict(first_dtype=I64), "first_new_page"),
+        (dict(first_n=B - 1), "first_new_page has"),
+        (dict(ids_rows=3), "block_ids"),
+        (dict(block_size=1024), "blockSize"),
+        (dict(l1_dtype=F32), "l1_cent must be"),
+    ]:
+        st, _, msg = call(**kw)
+        assert st == PARAM_INVALID and fragment in msg, (kw.keys(), msg)

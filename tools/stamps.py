@@ -62,19 +62,20 @@ except RuntimeError:
 _ok = d_attn[:, 1, 8] > 0
 if _ok.any():
     _idx = np.nonzero(_ok)[0]
-    _dur = d_attn[:, :, 10].max(axis=1)[_ok] - d_attn[_ok, 1, 8]
+    _dur = d_attn[:, :, 9].max(axis=1)[_ok] - d_attn[_ok, 1, 8]
     print("attention only, duration by blockIdx % 8 (mean): " + " ".join(f"{c}:{_dur[_idx % 8 == c].mean():.0f}" for c in range(8)))
 for it in range(5):
     row = d_attn[:, it, :]
     ms = (row[:, 9] > 0) & (row[:, 8] > 0)
     if ms.any():
         print(f"item#{it}: n={int(ms.sum())} stream={np.median(row[ms, 9] - row[ms, 8]):.0f} "
-              f"wait_after_stream={np.median(row[ms, 10] - row[ms, 9]):.0f} first_start={np.median(row[ms, 8]) - d_attn[d_attn > 0].min():.0f}")
+              f"first_start={np.median(row[ms, 8]) - d_attn[d_attn > 0].min():.0f}")
 d = report("fused", plan.run)
 row = d[:, 0, :]
 ok = row[:, 11] > 0
 t_first = row[ok, 11].min()
-ends = d[:, :15, 10].max(axis=1)[ok] - row[ok, 11]   # s_memtime bases differ between XCDs: only own-start deltas
+_last = np.where(d[:, 15, 2] > 0, d[:, 15, 2], d[:, :15, 9].max(axis=1))   # kernel end (tail protocol done) of wave 0
+ends = _last[ok] - row[ok, 11]   # s_memtime bases differ between XCDs: only own-start deltas
 print(f"prologue: start-spread(p50/max)={np.median(row[ok, 11] - t_first):.0f}/{(row[ok, 11] - t_first).max():.0f} "
       f"score={np.median(row[ok, 12] - row[ok, 11]):.0f} "
       f"rows={np.median((row[ok, 13] - row[ok, 12])[row[ok, 13] > 0]) if (row[ok, 13] > 0).any() else 0:.0f} "
@@ -86,8 +87,10 @@ print("duration by blockIdx % 8 (mean, min, max): " + " | ".join(
     f"{c}: {ends[idx % 8 == c].mean():.0f} {ends[idx % 8 == c].min():.0f} {ends[idx % 8 == c].max():.0f}" for c in range(8)))
 half = len(idx) // 2
 print(f"first half of the grid mean {ends[idx < half].mean():.0f}, second half {ends[idx >= half].mean():.0f}")
-per_item = d[:, 1:5, 9] - d[:, 1:5, 8]
-print("stream ticks by item position (median): " + " ".join(f"{np.median(per_item[ok, j][per_item[ok, j] > 0]):.0f}" for j in range(4)))
+per_item = d[:, 1:6, 9] - d[:, 1:6, 8]
+print("stream ticks by item position (median): " + " ".join(f"{np.median(per_item[ok, j][per_item[ok, j] > 0]):.0f}" for j in range(5) if (per_item[ok, j] > 0).any()))
+gaps = d[:, 2:6, 8] - d[:, 1:5, 9]
+print("wave 0 gap between items (median): " + " ".join(f"{np.median(gaps[ok, j][(d[ok, 2 + j, 8] > 0)]):.0f}" for j in range(4) if (d[ok, 2 + j, 8] > 0).any()))
 t15 = d[:, 15, :]
 if (t15[ok, 0] > 0).any():
     print(f"tail: loop exit -> own arrival {np.median(t15[ok, 1] - t15[ok, 0]):.0f}, helping {np.median(t15[ok, 2] - t15[ok, 1]):.0f} "
@@ -110,5 +113,5 @@ for it in range(5):
             parts.append(f"{n}={np.median(row[m, j] - row[m, i]):.0f}")
     ms = ok & (row[:, 9] > 0) & (row[:, 8] > 0)
     if ms.any():
-        parts.append(f"stream={np.median(row[ms, 9] - row[ms, 8]):.0f} wait_after_stream={np.median(row[ms, 10] - row[ms, 9]):.0f} start={np.median(row[ms, 8]) - d[d > 0].min():.0f}")
+        parts.append(f"stream={np.median(row[ms, 9] - row[ms, 8]):.0f} start={np.median(row[ms, 8]) - d[d > 0].min():.0f}")
     print(f"item#{it}: n={int(ok.sum())} " + " ".join(parts))
