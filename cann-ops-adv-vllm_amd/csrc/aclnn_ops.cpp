@@ -65,6 +65,7 @@ thread_local int g_shared_scoring = 1;
 thread_local int64_t g_page_size = 128;   // PAGESIZE of cent_select.cpp:17 / select_position.cpp:112
 thread_local const long long* g_act_seq_dev = nullptr;   // one-shot, consumed by the next attention plan
 thread_local int64_t g_act_seq_dev_n = 0;
+thread_local int g_token_positions = 0;      // one-shot: the next attention plan reads blockposition as token indices
 thread_local void* g_debug_buf = nullptr;   // diagnostic stamp buffer (see spfaSetDebugBuffer)
 
 constexpr size_t kMaxLds = 160 * 1024;    // LDS per CU on gfx950
@@ -310,6 +311,7 @@ aclnnStatus spfaSetActualSeqLengthsDevice(const int64_t* dev, int64_t n) {
     g_act_seq_dev_n = dev ? n : 0;
     return ACLNN_SUCCESS;
 }
+aclnnStatus spfaSetTokenPositions(int enable) { g_token_positions = enable ? 1 : 0; return ACLNN_SUCCESS; }
 aclnnStatus spfaSetWorkspacePersistent(aclOpExecutor* e, int enable) {
     if (!e) return fail(ACLNN_ERR_PARAM_NULLPTR, "executor is NULL");
     if (enable && !e->repeatable) return fail(ACLNN_ERR_PARAM_INVALID, "only a repeatable executor can keep a workspace");
@@ -706,7 +708,7 @@ static size_t carve_lds(spfa::AttnParams& p, size_t nq) {
 static aclnnStatus plan_lds(spfa::AttnParams& p) {
     const bool per_head = (p.mode == 0 && p.pos_rows == p.Hq && p.G > 1);
     // pseShift / attenMask index the columns of ONE head's list: every q head runs as its own pass
-    int nq = (per_head || p.pse || p.amask) ? 1 : spfa::attention_rows_per_pass(p.G, p.kv_dtype, p.D);
+    int nq = (per_head || p.pse || p.amask || p.token_mode) ? 1 : spfa::attention_rows_per_pass(p.G, p.kv_dtype, p.D);
     size_t need = carve_lds(p, (size_t)nq);
     // a large group with many clusters: fewer q heads per pass (more passes over the pages) until the keys fit
     while (need > kMaxLds && nq > 2 && spfa::attention_uses_mfma(nq, p.kv_dtype, p.D)) {
@@ -747,7 +749,8 @@ static void plan_workspace(aclOpExecutor* e) {
         long long ns = n_cu / items;
         if (ns < 2) ns = 2;
         if (ns > g_max_split) ns = g_max_split;
-        if (ns > p.max_entries) ns = p.max_entries;   // at least one page per share
+        const long long list_pages = p.token_mode ? p.max_entries / p.block_size : p.max_entries;
+        if (ns > list_pages) ns = list_pages;   // at least one page per share
         if (ns > 1) p.n_split = (int)ns;
     }
     // Which class (item % 8 = kv head % 8 when Hkv is a multiple of 8) a workgroup's claims start with.  Staying with
@@ -765,7 +768,7 @@ static void plan_workspace(aclOpExecutor* e) {
     // group's lists varies from item to item): measured 2.4 % faster with sharing at 2 items per workgroup.
     const bool mfma = spfa::attention_uses_mfma(p.rows_per_pass, p.kv_dtype, p.D);
     const bool worth = items >= 6ll * n_cu || (items > n_cu && (p.max_entries >= 512 || mfma));
-    p.tail_on = (g_tail_sharing && p.n_split == 1 && n_cu > 0 && (worth || g_tail_sharing == 2)) ? 1 : 0;
+    p.tail_on = (g_tail_sharing && p.n_split == 1 && n_cu > 0 && !p.token_mode && (worth || g_tail_sharing == 2)) ? 1 : 0;
     p.dyn_pages = g_tail_sharing ? 1 : 0;   // spfaSetTailSharing(0) asks for a reproducible summation order
     const uint64_t n_boards = p.tail_on ? (uint64_t)(cap > 0 ? cap : 2ll * n_cu) : 0;   // one per resident workgroup
     const uint64_t state_bytes = (uint64_t)p.rows_per_pass * (p.D + 2) * 4;
@@ -830,6 +833,8 @@ aclnnStatus aclnnSparsePagedAttentionGetWorkspaceSize(
     const int64_t act_seq_dev_n = g_act_seq_dev_n;
     g_act_seq_dev = nullptr;
     g_act_seq_dev_n = 0;
+    const int token_positions = g_token_positions;
+    g_token_positions = 0;
     REQUIRE_PTR(workspaceSize, "workspaceSize");
     REQUIRE_PTR(executor, "executor");
     REJECT_PRESENT(dequantScale1, "dequantScale1");   // int8 queries are not part of this path
@@ -854,6 +859,18 @@ aclnnStatus aclnnSparsePagedAttentionGetWorkspaceSize(
     p.pos_rows = rows;
     p.P = (int)blockposition->dims[2];
     p.max_entries = p.P;
+    if (token_positions) {
+        // token-level lists (the variant sketched in the reference's tests/ifa_v5_case_tkp.py:53-54): one 8-byte entry per
+        // token in LDS, padded to whole virtual pages of blockSize entries
+        const int lpt_tok = p.D * (p.kv_dtype == spfa::kI8 ? 1 : 2) / 16;
+        if (p.D != 64 && p.D != 128)
+            return bail(fail(ACLNN_ERR_PARAM_INVALID, "token-level positions support head dims 64 and 128, got %d", p.D));
+        (void)lpt_tok;
+        if (!absent(pseShift) || !absent(attenMask))
+            return bail(fail(ACLNN_ERR_PARAM_INVALID, "pseShift / attenMask are not supported with token-level positions"));
+        p.token_mode = 1;
+        p.max_entries = round_up(p.P, p.block_size);
+    }
     p.act_seq_uniform = -1;
     if (act_seq_dev) {   // extension: lengths already on the device, no host round trip
         if (act_seq_dev_n < p.B)

@@ -44,6 +44,7 @@ namespace {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 // readfirstlane makes the wave index provably uniform for the compiler: everything derived from it
@@ -131,9 +132,9 @@ hipError_t ensure_lds_limit(const void* kern, int* table, size_t bytes) {
 
 // cap_out != nullptr (phase 1): set the LDS limit, ask the runtime how many workgroups fit a CU, report the resident
 // grid.  Otherwise (phase 2): launch; with p.grid_cap from phase 1 this is nothing but the launch itself.
-template <typename KVT, int NQ, int LPT, bool MFMA>
+template <typename KVT, int NQ, int LPT, bool MFMA, bool TOK = false>
 hipError_t launch_attn_one(const AttnParams& p, hipStream_t s, long long* cap_out) {
-    auto kern = attn_kernel<KVT, NQ, LPT, MFMA>;
+    auto kern = attn_kernel<KVT, NQ, LPT, MFMA, TOK>;
     static int lds_limit[kMaxDevices];
     long long cap = p.grid_cap;
     if (cap_out || cap <= 0) {
@@ -290,6 +291,26 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t s, long long* cap_o
     const int nq = p.rows_per_pass;
     const int esize = (p.kv_dtype == kI8) ? 1 : 2;
     const int lpt = p.D * esize / 16;
+#ifndef SPFA_EXPLORE
+    if (p.token_mode) {   // token-level lists: one q head per pass, head dims 64 and 128
+        if (nq != 1 || p.mode != 0) return hipErrorInvalidValue;
+        switch (p.kv_dtype) {
+            case kF16:
+                if (lpt == 16) return launch_attn_one<_Float16, 1, 16, false, true>(p, s, cap_out);
+                if (lpt == 8) return launch_attn_one<_Float16, 1, 8, false, true>(p, s, cap_out);
+                break;
+            case kBF16:
+                if (lpt == 16) return launch_attn_one<__bf16, 1, 16, false, true>(p, s, cap_out);
+                if (lpt == 8) return launch_attn_one<__bf16, 1, 8, false, true>(p, s, cap_out);
+                break;
+            case kI8:
+                if (lpt == 8) return launch_attn_one<int8_t, 1, 8, false, true>(p, s, cap_out);
+                if (lpt == 4) return launch_attn_one<int8_t, 1, 4, false, true>(p, s, cap_out);
+                break;
+        }
+        return hipErrorInvalidValue;
+    }
+#endif
     if (attention_uses_mfma(nq, p.kv_dtype, p.D)) {
         if (nq > 16) return hipErrorInvalidValue;
 #ifdef SPFA_EXPLORE

@@ -101,6 +101,10 @@ struct AttnParams {
     int quant2_dtype;          // kF32 | kBF16
     int quant2_per_channel;    // 1: [Hq * D]
     // mode 0
+    // 1: block_position holds LOGICAL TOKEN indices (sentinel terminated; token t lives in row t % block_size of page
+    // block_table[b][t / block_size]) and actual_seq_lengths counts tokens, the token-level variant sketched in the
+    // reference's tests/ifa_v5_case_tkp.py:53-54; 0: logical page indices
+    int token_mode;
     const int32_t* block_position; // [B, rows, P]
     int pos_rows;                  // Hq or Hkv
     const long long* act_seq;      // device [B] or null

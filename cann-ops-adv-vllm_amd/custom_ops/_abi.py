@@ -59,6 +59,7 @@ spfaSetTailSharing = _sig("spfaSetTailSharing", c_int, [c_int])
 spfaSetSharedScoring = _sig("spfaSetSharedScoring", c_int, [c_int])
 spfaSetPageSize = _sig("spfaSetPageSize", c_int, [c_int64])
 spfaSetActualSeqLengthsDevice = _sig("spfaSetActualSeqLengthsDevice", c_int, [c_void_p, c_int64])
+spfaSetTokenPositions = _sig("spfaSetTokenPositions", c_int, [c_int])
 spfaSetWorkspacePersistent = _sig("spfaSetWorkspacePersistent", c_int, [T, c_int])
 spfaVersion = _sig("spfaVersion", c_char_p, [])
 

@@ -131,7 +131,7 @@ def sparse_paged_attention(query: torch.Tensor, key: torch.Tensor, value: torch.
                            antiquant_offset: torch.Tensor, blocktable: torch.Tensor, kv_padding_size: torch.Tensor,
                            blockposition: torch.Tensor, num_heads: int, scale_value: float, input_layout: str,
                            num_key_value_heads: int, block_size: int, inner_precise: int,
-                           *, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+                           *, out_dtype: Optional[torch.dtype] = None, token_level: bool = False) -> torch.Tensor:
     """Decode attention over the pages listed in blockposition (add_custom.py:41-75; binding
     sparse_paged_attention_impl_npu wraps key/value into one-tensor lists and returns a tensor shaped
     like query).  out_dtype=torch.float32 (extra) returns the un-rounded result.
@@ -141,7 +141,11 @@ def sparse_paged_attention(query: torch.Tensor, key: torch.Tensor, value: torch.
     sequence, list slot * block_size + token.  quant_scale2 / quant_offset2 (float32 or bfloat16; one value or
     num_heads * D) turn the output into int8.  antiquant_scale / antiquant_offset may be [2, Hkv, D] (per channel)
     or [2] (per tensor).  dequant_scale1, quant_scale1 and dequant_scale2 must be empty; kv_padding_size is ignored (paged KV
-    has no left padding, sparse_paged_fusion_attention_tiling_check.cc:590-594)."""
+    has no left padding, sparse_paged_fusion_attention_tiling_check.cc:590-594).
+
+    token_level=True (extra; the variant sketched in the reference's tests/ifa_v5_case_tkp.py:53-54): blockposition
+    [B, num_heads | num_key_value_heads, max_tokens] holds logical TOKEN indices (sentinel terminated; token t is row
+    t % block_size of page blocktable[b][t // block_size]) and actual_seq_lengths counts tokens."""
     _abi.require_gpu(query, key, value, blocktable, blockposition)
     dev = query.device
     out = torch.empty(query.shape, dtype=out_dtype or _default_out_dtype(query, quant_scale2), device=dev)
@@ -157,6 +161,7 @@ def sparse_paged_attention(query: torch.Tensor, key: torch.Tensor, value: torch.
         # last, right in front of phase 1 (which consumes it): the device-resident lengths are a one-shot setting
         seq_arr, dev_lengths = _seq_lengths_arg(actual_seq_lengths, dev)
         arrays = [seq_arr]
+        _abi.check(_abi.spfaSetTokenPositions(1 if token_level else 0), "spfaSetTokenPositions")
         args = tens[:1] + lists + opt + [seq_arr] + quant + [
             int(num_heads), float(scale_value), str(input_layout).encode(), int(num_key_value_heads), int(block_size),
             int(inner_precise), tens[1]]
@@ -164,6 +169,7 @@ def sparse_paged_attention(query: torch.Tensor, key: torch.Tensor, value: torch.
                  "aclnnSparsePagedAttention")
     finally:
         _abi.spfaSetActualSeqLengthsDevice(None, 0)
+        _abi.spfaSetTokenPositions(0)
         _destroy(tens + opt + quant, lists, arrays)
     if dev_lengths is not None:
         dev_lengths.record_stream(torch.cuda.current_stream(dev))

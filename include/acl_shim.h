@@ -120,6 +120,12 @@ SPFA_API aclnnStatus spfaSetPageSize(int64_t pageSize);
  * from this DEVICE array of n int64 instead of the host aclIntArray (the reference's binding copies a
  * device tensor to the host first, add_custom.cpp:105-118). */
 SPFA_API aclnnStatus spfaSetActualSeqLengthsDevice(const int64_t* deviceLengths, int64_t n);
+/* One-shot: the next aclnnSparsePagedAttentionGetWorkspaceSize on this thread reads `blockposition` [B, numHeads |
+ * numKeyValueHeads, maxTokens] as LOGICAL TOKEN indices instead of page indices (token t = row t % blockSize of page
+ * blocktable[b][t / blockSize]; a row ends at its first 0x7fffffff) and actualSeqLengths as token counts — the
+ * token-level variant the reference sketches in tests/ifa_v5_case_tkp.py:53-54.  Head dims 64 and 128; pseShift /
+ * attenMask are refused; every q head is streamed as its own pass. */
+SPFA_API aclnnStatus spfaSetTokenPositions(int enable);
 /* A launch of the two attention ops starts with a small kernel that zeroes the counters at the head of the workspace;
  * the op's kernel leaves them zeroed again when it ends.  enable = 1 on a repeatable executor of
  * SparsePagedFusionAttention promises that nothing but this executor's launches writes the workspace between

@@ -191,7 +191,7 @@ def sparse_paged_attention(q, key_cache, value_cache, block_table, block_positio
                            antiquant_scale=None, antiquant_offset=None,
                            token_limit=None, p_round: str | None = None,
                            exact: bool = True, pse_shift=None, atten_mask=None,
-                           quant_scale2=None, quant_offset2=None) -> np.ndarray:
+                           quant_scale2=None, quant_offset2=None, token_level: bool = False) -> np.ndarray:
     """Decode attention over a virtual sequence of selected pages.  Returns fp32 [B,Hq,D].
 
     Virtual token t of batch b / head row r lives in virtual page j = t // bs; its
@@ -218,6 +218,10 @@ def sparse_paged_attention(q, key_cache, value_cache, block_table, block_positio
     (non zero = masked) then replaces them by -1e12 (…Us2.h:3363-3404, :860); both are
     indexed by the COLUMN of the gathered sequence, j * block_size + i for token i of the
     j-th list slot (:2192-2194, 2239-2244).
+
+    token_level=True: block_position holds logical TOKEN indices (the variant sketched in the
+    reference's tests/ifa_v5_case_tkp.py:53-54): entry j < actual_seq_lengths[b] before the first
+    0x7fffffff is token t, row t % bs of page block_table[b, t // bs].
 
     quant_scale2 / quant_offset2 (scalar or [Hq * D]): int8 output,
     out * scale2 + offset2 in fp32, cast to f16 and then to int8, both with ties away from
@@ -261,6 +265,23 @@ def sparse_paged_attention(q, key_cache, value_cache, block_table, block_positio
             if quant:
                 qv = qv * a_s[0, n2].astype(facc)
             ks, vs, cols = [], [], []
+            if token_level:
+                n_tok = P if actual_seq_lengths is None else int(actual_seq_lengths[b])
+                n_ent = min(int(sent[0]) if sent.size else P, max(0, n_tok))
+                toks = row[:n_ent].astype(np.int64)
+                bad = np.nonzero((toks < 0) | (toks >= bt.shape[1] * block_size))[0]
+                if bad.size:
+                    toks = toks[:int(bad[0])]
+                if toks.size:
+                    blk = np.clip(bt[b, toks // block_size], 0, key_cache.shape[0] - 1)
+                    kc = key_cache.reshape(key_cache.shape[0], -1, Hkv, D) if kv_layout == "BSH" else \
+                        key_cache.reshape(key_cache.shape[0], Hkv, -1, D).transpose(0, 2, 1, 3)
+                    vc = value_cache.reshape(value_cache.shape[0], -1, Hkv, D) if kv_layout == "BSH" else \
+                        value_cache.reshape(value_cache.shape[0], Hkv, -1, D).transpose(0, 2, 1, 3)
+                    ks.append(kc[blk, toks % block_size, n2])
+                    vs.append(vc[blk, toks % block_size, n2])
+                    cols.append(np.arange(toks.size))
+                n_pages = 0
             for j in range(n_pages):
                 p = int(row[j])
                 blk = int(bt[b, p])

@@ -1,0 +1,50 @@
+"""A compiled C++ program written against include/*.h only (tests/cpp/ref_caller.cpp, built by
+__graft_entry__.build()) drives the library the way the reference's own C++ callers do: the fused op with the call
+sequence of extension/csrc/add_custom.cpp:770-935 (descriptors for all 22 operands, repeatable executor, workspace,
+repeated launch, destroy) and compute_cent with the flow of
+src/transformer/compute_cent/test/test_compute_cent.cpp:150-260.  Its outputs are checked against the oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import datagen
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CALLER = os.path.join(ROOT, "tests", "cpp", "ref_caller")
+
+
+def test_caller_is_built_and_binds_without_a_gpu():
+    assert os.path.exists(CALLER), "tests/cpp/ref_caller is missing: run __graft_entry__.build() (make -C tests/cpp)"
+    r = subprocess.run([CALLER, "--abi-check"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "abi ok" in r.stdout
+
+
+@pytest.mark.gpu
+def test_reference_call_sequence_gives_the_oracle_results(tmp_path):
+    from oracle import ref
+    from parity import rel_err
+    B, Hq, Hkv, D, C, k, bs, max_page, kv_page_len = 5, 8, 2, 128, 256, 8, 128, 24, 96
+    seq_lens = [24 * 128, 3000, 129, 1, 2000]
+    q, l1 = datagen.cent_case(41, B, Hq, Hkv, D, C, True)
+    ids, table, seq = datagen.page_case(41, Hkv, C, kv_page_len, B, max_page, seq_lens)
+    kc, vc = datagen.kv_case(41, kv_page_len, bs, Hkv, D, "BSH", dist="randn")
+    for name, a in (("q", q), ("l1", l1), ("key", kc), ("val", vc), ("table", table), ("ids", ids), ("seq", seq)):
+        np.ascontiguousarray(a).tofile(tmp_path / f"{name}.bin")
+    meta = dict(B=B, Hq=Hq, Hkv=Hkv, D=D, C=C, k=k, bs=bs, max_page=max_page, n_blocks=kv_page_len,
+                kv_page_len=kv_page_len, P=256)
+    (tmp_path / "meta.txt").write_text("".join(f"{key} {val}\n" for key, val in meta.items()))
+    r = subprocess.run([CALLER, str(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    want, wpos, wlen, wmax = ref.sparse_paged_fusion_attention(q, kc, vc, table, l1, ids, seq, Hq, Hkv, D ** -0.5, bs, k, 256)
+    load = lambda name, dt, shape: np.fromfile(tmp_path / f"{name}.bin", dtype=dt).reshape(shape)
+    assert np.array_equal(load("indices", np.int32, (B, Hq, k)), ref.compute_cent(q, l1, k))
+    assert np.array_equal(load("pos", np.int32, (B, Hq, 256)), wpos)
+    assert np.array_equal(load("plen", np.int32, (B, Hq, 8)), wlen)
+    assert np.array_equal(load("pmax", np.int64, (B, 8)), wmax)
+    got = load("out", np.float16, (B, Hq, D)).astype(np.float32)
+    # f16 output: one rounding (2^-11) on top of the 1e-3 bound on the fp32 result; elements below 1 % of the largest
+    # output are measured against that floor
+    assert rel_err(got, want).max() <= 1e-3 + 2.0 ** -11
