@@ -166,13 +166,12 @@ int to_dtype(aclDataType t) {
 
 int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
-// q rows scored per centroid pass by the standalone scoring ops: the keys [rows][Cp] u32 and the waves' centroid
-// tiles share an 84 KiB budget (8 rows at C = 2048, D = 128; measured faster than 7 rows with two workgroups per
-// CU), at most 16 rows (one MFMA tile).  When a whole group fits, rows of several sequences share the pass, dealt
+// q rows scored per centroid pass by the standalone scoring ops: the keys [rows][Cp] u32 and the eight waves' centroid
+// tiles share a 100 KiB budget (8 rows at C = 2048, D = 128: one row per wave), at most 16 rows (one MFMA tile).  When a whole group fits, rows of several sequences share the pass, dealt
 // evenly over the workgroups of a kv head.
 void plan_cent_rows(spfa::CentParams& p) {
 #ifndef SPFA_CENT_BUDGET_KB
-#define SPFA_CENT_BUDGET_KB 84
+#define SPFA_CENT_BUDGET_KB 100
 #endif
     int r = (SPFA_CENT_BUDGET_KB * 1024 - spfa::cent_stage_bytes(p.D)) / (p.Cp * 4);
     if (r < 1) r = 1;
@@ -352,7 +351,7 @@ aclnnStatus aclnnComputeCentGetWorkspaceSize(const aclTensor* query, const aclTe
     p.indices = (int32_t*)data_ptr(indicesOut);
     int npow2 = 64;
     while (npow2 < k) npow2 <<= 1;
-    p.lds_bytes = (size_t)p.rows_per_pass * p.Cp * 4 + (size_t)4 * npow2 * 8 + (size_t)spfa::cent_stage_bytes(p.D);
+    p.lds_bytes = (size_t)p.rows_per_pass * p.Cp * 4 + (size_t)spfa::kCentWaves * npow2 * 8 + (size_t)spfa::cent_stage_bytes(p.D);
     *workspaceSize = 0;
     *executor = e;
     return ACLNN_SUCCESS;
@@ -471,7 +470,7 @@ aclnnStatus aclnnCentSelectGetWorkspaceSize(const aclTensor* query, const aclTen
     p.page_position = (int32_t*)data_ptr(pagePositionOut);
     p.page_position_length = (int32_t*)data_ptr(pagePositionLengthOut);
     p.max_page_position_length = (unsigned long long*)data_ptr(maxPagePositionLengthOut);
-    p.lds_bytes = (size_t)p.rows_per_pass * p.Cp * 4 + (size_t)4 * (p.Cp / 32) * 4 + (size_t)spfa::cent_stage_bytes(p.D);
+    p.lds_bytes = (size_t)p.rows_per_pass * p.Cp * 4 + (size_t)spfa::kCentWaves * (p.Cp / 32) * 4 + (size_t)spfa::cent_stage_bytes(p.D);
     *workspaceSize = 0;
     *executor = e;
     return ACLNN_SUCCESS;

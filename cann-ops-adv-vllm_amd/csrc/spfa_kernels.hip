@@ -278,7 +278,8 @@ int attention_stream_waves(bool mfma, int kv_dtype) { return stream_waves(mfma, 
 int attention_stage_bytes(bool mfma, int kv_dtype, int D) {
     return (mfma ? sel_waves(true) : stream_waves(false, kv_dtype == kI8) + sel_waves(false)) * score_stage_bytes(D);
 }
-int cent_stage_bytes(int D) { return 4 * score_stage_bytes(D); }
+int cent_stage_bytes(int D) { return kCentWaves * score_stage_bytes(D); }
+int assign_stage_bytes(int D) { return 4 * score_stage_bytes(D); }
 
 int attention_rows_per_pass(int G, int kv_dtype, int D) {
     if (G <= 1) return 1;
@@ -351,15 +352,15 @@ static hipError_t launch_cent(const CentParams& p, int mode, hipStream_t s) {
     static int lds_limit[2][kMaxDevices];
     const hipError_t le = ensure_lds_limit(kern, lds_limit[mode], p.lds_bytes);
     if (le != hipSuccess) return le;
-    if (mode == 0) hipLaunchKernelGGL(cent_kernel<0>, grid, dim3(kThreads), p.lds_bytes, s, p);
-    else hipLaunchKernelGGL(cent_kernel<1>, grid, dim3(kThreads), p.lds_bytes, s, p);
+    if (mode == 0) hipLaunchKernelGGL(cent_kernel<0>, grid, dim3(kCentWaves * 64), p.lds_bytes, s, p);
+    else hipLaunchKernelGGL(cent_kernel<1>, grid, dim3(kCentWaves * 64), p.lds_bytes, s, p);
     return hipGetLastError();
 }
 hipError_t launch_compute_cent(const CentParams& p, hipStream_t s) { return launch_cent(p, 0, s); }
 hipError_t launch_cent_select(const CentParams& p, hipStream_t s) { return launch_cent(p, 1, s); }
 
 size_t assign_lds_bytes(int rows_per_pass, int Cp, int D) {
-    return (size_t)rows_per_pass * Cp * 4 + (size_t)16 * D * 2 + 16 * sizeof(AssignSlot) + 16 + (size_t)cent_stage_bytes(D);
+    return (size_t)rows_per_pass * Cp * 4 + (size_t)16 * D * 2 + 16 * sizeof(AssignSlot) + 16 + (size_t)assign_stage_bytes(D);
 }
 hipError_t launch_assign(const AssignParams& p, hipStream_t s) {
     const long long groups = ((long long)p.B * p.max_new + p.rows_per_pass - 1) / p.rows_per_pass;

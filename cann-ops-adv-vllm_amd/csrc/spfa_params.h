@@ -11,6 +11,8 @@ namespace spfa {
 constexpr int kSentinel = 0x7fffffff;   // cent_select.cpp:406
 constexpr int kLenPad = 8;              // page_position_length / max_page_position_length lanes
 constexpr int kThreads = 256;           // 4 wave64 per workgroup
+constexpr int kCentWaves = 8;           // waves per workgroup of the standalone scoring kernels: one q row each after
+                                        // the shared centroid pass (8 rows per pass at C = 2048)
 
 enum DType : int { kF16 = 0, kBF16 = 1, kI8 = 2, kF32 = 3 };
 
@@ -186,6 +188,7 @@ int attention_stream_waves(bool mfma, int kv_dtype);
 // LDS tiles through which the centroid pass turns memory order into matrix-core operand order: bytes at off_stage of
 // the attention kernels, and at the end of the dynamic LDS of the cent kernels.
 int attention_stage_bytes(bool mfma, int kv_dtype, int D);
-int cent_stage_bytes(int D);
+int cent_stage_bytes(int D);      // kCentWaves tiles
+int assign_stage_bytes(int D);    // 4 tiles
 
 }  // namespace spfa
