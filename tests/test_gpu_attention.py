@@ -133,6 +133,11 @@ def test_attention_vs_oracle(H, dtype, layout, Hq, Hkv, rows, D, bs, seq_mode):
     tol2 = 2e-3 if dtype == "f16" else 1.5e-2
     dev2 = float(np.abs(want2 - want).max() / np.abs(want).max())
     assert dev2 <= tol2, dev2
+    # ... and so does the kernel against it: the reference rounds P to the KV dtype before P.V (…Us2.h:3567-3568), the
+    # kernel keeps P in fp32 (or a high + low pair), so the two differ by that rounding, measured against the largest
+    # output of the tensor (V is zero-mean here, element-wise relative errors are meaningless near the zeros)
+    dev3 = float(np.abs(out32 - want2).max() / np.abs(want2).max())
+    assert dev3 <= tol2, dev3
 
 
 def test_dense_equivalence_vs_torch_sdpa(H):
@@ -327,9 +332,11 @@ def test_page_list_split_equals_single_workgroup(H, Hq, Hkv, kvdt):
         alone = H.call_fusion(qd, kd, vd, td, l1d, idsd, seqd, Hq, Hkv, D ** -0.5, bs, topk, out_dtype=torch.float32, **kw)
     finally:
         _abi.spfaSetSharedScoring(1)
-    assert all(torch.equal(x, y) for x, y in zip(alone, res[16]))
     out1, pos1, len1, max1 = res[1]
     scale = float(out1.abs().max())
+    # integer outputs bit for bit; the attention up to the order in which the waves claimed their pages
+    assert all(torch.equal(x, y) for x, y in zip(alone[1:], res[16][1:]))
+    assert float((alone[0] - res[16][0]).abs().max()) <= 2e-6 * scale
     for ms in (16, 3):
         out, pos, plen, pmax = res[ms]
         assert torch.equal(pos, pos1) and torch.equal(plen, len1) and torch.equal(pmax, max1)

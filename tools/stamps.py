@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Diagnostic: per-phase cycle shares of the item pipeline (needs a -DSPFA_STAMPS library build)."""
+"""Diagnostic: timeline of the item pipeline from in-kernel stamps (needs a -DSPFA_STAMPS library build).  The stamps are
+s_memrealtime values: ticks of a constant 100 MHz clock, i.e. 10 ns each."""
 import ctypes
 import os
 import sys
