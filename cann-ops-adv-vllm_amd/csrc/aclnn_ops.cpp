@@ -679,14 +679,15 @@ constexpr uint64_t kCounterBytes = 256;   // 8 work counters at the start of the
 static size_t carve_lds(spfa::AttnParams& p, size_t nq) {
     auto align16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
     size_t off = 0;
+    const size_t sel_rows = nq * (size_t)(p.pre_items > 1 ? p.pre_items : 1);   // rows whose selection is held at once
     p.off_keys = (int)off;
-    if (p.mode == 1) off += align16(nq * p.Cp * 4);                        // score keys (selector wave)
+    if (p.mode == 1) off += align16(sel_rows * p.Cp * 4);                  // score keys (selector wave)
     p.off_cbits = (int)off;
     const size_t max_waves = 8;   // upper bound of the waves of a workgroup (streamers + selectors)
     if (p.mode == 1)   // top-k cluster bitmaps (one per wave that selects a row of the first item) + 16 row lengths
-        off += align16((nq < max_waves ? nq : max_waves) * (size_t)(p.Cp / 32) * 4) + 64;
+        off += align16((sel_rows < max_waves ? sel_rows : max_waves) * (size_t)(p.Cp / 32) * 4) + 64;
     p.off_pbits = (int)off;
-    if (p.mode == 1) off += align16(nq * ((p.max_page + 63) / 64) * 8);    // per-head page bitmaps
+    if (p.mode == 1) off += align16(sel_rows * ((p.max_page + 63) / 64) * 8);   // per-head page bitmaps
     p.off_list = (int)off;
     off += align16((size_t)2 * p.max_entries * 8);                         // double-buffered page lists
     p.off_comb = (int)off;
@@ -716,6 +717,7 @@ static aclnnStatus plan_lds(spfa::AttnParams& p) {
     }
     p.rows_per_pass = nq;
     p.lds_bytes = need;
+    p.pre_items = 0;
     REQUIRE(p.lds_bytes <= kMaxLds, "page list of %d entries / %d clusters needs %zu bytes of LDS (> %zu)", p.max_entries,
             p.C, p.lds_bytes, kMaxLds);
     return ACLNN_SUCCESS;
@@ -751,6 +753,26 @@ static void plan_workspace(aclOpExecutor* e) {
         const long long list_pages = p.token_mode ? p.max_entries / p.block_size : p.max_entries;
         if (ns > list_pages) ns = list_pages;   // at least one page per share
         if (ns > 1) p.n_split = (int)ns;
+    }
+    // Fused op, one pass per (sequence, kv head), a launch of exactly J items per resident workgroup with the workgroup count a
+    // multiple of the kv heads: workgroup w then owns items w, w + grid, ... — J sequences of ONE kv head — and scores
+    // their J rows in one pass over that head's centroids (the MFMA tile has 16 rows and one pass costs the same for 1
+    // or 16 of them), instead of J passes of which J - 1 run beside the page stream and slow it down.  Taken only when
+    // the larger key area leaves the residency (and with it the grid) unchanged.  Measured: int8 S=64k 0.780 -> 0.767 ms,
+    // configs[2] equal within noise (its second item gains 5 us, the first selection grows by 3 us).  Group passes, which the
+    // kernel would take as well (J * R <= 16 rows), lose: GQA 32/8 S=32k 0.241 -> 0.242 ms, S=128k k=64 0.752 -> 0.767 ms —
+    // their first selection walks J * R rows with 6 or 8 waves, all of it exposed.
+    p.pre_items = 0;
+    if (g_shared_scoring && p.mode == 1 && p.n_split == 1 && cap > 0 && items > cap && items % cap == 0 &&
+        p.rows_per_pass == 1 && p.G == 1 && cap % p.Hkv == 0 && items / cap <= 8) {
+        spfa::AttnParams trial = p;
+        trial.pre_items = (int)(items / cap);
+        trial.lds_bytes = carve_lds(trial, (size_t)p.rows_per_pass);
+        long long cap2 = 0;
+        if (trial.lds_bytes <= kMaxLds && spfa::launch_attention(trial, nullptr, &cap2) == hipSuccess && cap2 == cap) {
+            trial.grid_cap = cap;
+            p = trial;
+        }
     }
     // Which class (item % 8 = kv head % 8 when Hkv is a multiple of 8) a workgroup's claims start with.  Staying with
     // the own XCD's class keeps that XCD's centroids in its L2, but a kv head whose pages spread over more clusters

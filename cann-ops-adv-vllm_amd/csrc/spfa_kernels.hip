@@ -163,6 +163,10 @@ hipError_t launch_attn_one(const AttnParams& p, hipStream_t s, long long* cap_ou
     if (total == 0) return hipSuccess;
     if (p.n_split > 1 && total > cap) return hipErrorInvalidConfiguration;   // a split needs one workgroup per unit
     const dim3 grid((unsigned)(total < cap ? total : cap));
+    // pre-scored items: the kernel takes the grid as the distance between a workgroup's items
+    if (p.pre_items > 1 && (total != (long long)p.pre_items * grid.x || grid.x % (unsigned)p.Hkv != 0 || p.mode != 1 || g_eff > nq ||
+                            p.pre_items * nq > 16))
+        return hipErrorInvalidConfiguration;
     hipLaunchKernelGGL(kern, grid, dim3(attn_threads(MFMA, sizeof(KVT) == 1)), p.lds_bytes, s, p);
     return hipGetLastError();
 }

@@ -140,6 +140,9 @@ struct AttnParams {
     // 1: the streamer waves of a workgroup claim the pages of an item one by one from a counter in LDS (whoever is
     // free takes the next page); 0: wave w takes pages w, w + 4, ... which makes attention_out bit-reproducible
     int dyn_pages;
+    // > 1: every workgroup owns exactly pre_items items (its own index, then one grid further each time), all of one kv
+    // head: their rows are scored in ONE pass over the head's centroids before the first item is streamed
+    int pre_items;
     // page-list split for small batches: n_split workgroups per item (1: off)
     int n_split;
     // sharing of every workgroup's last item (n_split == 1 only): boards and their data areas in the workspace

@@ -109,9 +109,11 @@ SPFA_API aclnnStatus spfaSetMaxSplit(int64_t maxSplit);
  * it to pay (several items per workgroup, long lists, group passes); 2: on for every launch without a page-list
  * split. */
 SPFA_API aclnnStatus spfaSetTailSharing(int enable);
-/* Fused op with a page-list split: the workgroups of one item score its rows in one shared pass over the centroids
- * and exchange the score keys through the workspace (a bounded wait; a workgroup that gives up scores alone).
- * 0 turns it off.  Default on. */
+/* Fused op, shared passes over the centroids.  With a page-list split the workgroups of one item score its rows in
+ * one shared pass and exchange the score keys through the workspace (a bounded wait; a workgroup that gives up
+ * scores alone).  In a launch of exactly J items per resident workgroup (one q head per pass, workgroup count a
+ * multiple of the kv heads) every workgroup owns J sequences of one kv head and scores their J rows in one pass
+ * before it streams the first.  Outputs do not depend on the setting.  0 turns both off.  Default on. */
 SPFA_API aclnnStatus spfaSetSharedScoring(int enable);
 /* page size of the two ops without a blockSize attribute (CentSelect, SelectPosition); the reference
  * compiles in 128 (cent_select.cpp:17, select_position.cpp:112).  Default 128. */

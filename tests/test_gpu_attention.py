@@ -342,3 +342,43 @@ def test_page_list_split_equals_single_workgroup(H, Hq, Hkv, kvdt):
         assert torch.equal(pos, pos1) and torch.equal(plen, len1) and torch.equal(pmax, max1)
         assert float((out - out1).abs().max()) <= 2e-6 * scale
         assert float((res[("sep", ms)] - res[("sep", 1)]).abs().max()) <= 2e-6 * scale
+
+
+@pytest.mark.parametrize("B,kvdt", [(32, "f16"), (48, "i8"), (64, "f16")])
+def test_items_scored_ahead_equal_items_scored_one_by_one(H, B, kvdt):
+    """A launch of exactly J items per resident workgroup (32 kv heads, one q head per pass: 512 workgroups on a 256-CU
+    part, so B = 32 / 48 / 64 gives J = 2 / 3 / 4) scores the J rows of a workgroup in one pass over the head's
+    centroids before the first item is streamed.  Ragged lengths; compared with the oracle and with the same launch
+    under spfaSetSharedScoring(0), which scores every item when its turn comes: integer outputs bit for bit, the
+    attention up to the order in which waves claimed pages.  (On a part with another workgroup count the shapes simply
+    take the ordinary path and the test still holds.)"""
+    from custom_ops import _abi
+    Hq = Hkv = 32
+    D, C, topk, bs, kv_page_len, max_page = 128, 128, 8, 32, 96, 40
+    rng = datagen.rng_for(900 + B)
+    seq_lens = [int(x) for x in rng.integers(1, max_page * bs, size=B)]
+    seq_lens[0], seq_lens[B - 1] = max_page * bs, 1
+    q, l1, ids, table, seq, k, v = _fusion_case(300 + B, B, Hq, Hkv, D, C, seq_lens, kv_page_len, max_page, bs,
+                                                kv="i8" if kvdt == "i8" else "f16")
+    kd, vd = (H.dev(k), H.dev(v)) if kvdt == "i8" else (H.dev(k, torch.float16), H.dev(v, torch.float16))
+    qd, l1d, td, idsd, seqd = H.dev(q, torch.float16), H.dev(l1, torch.float16), H.dev(table), H.dev(ids), H.dev(seq)
+    kw, okw = {}, {}
+    if kvdt == "i8":
+        a_s, a_o = datagen.antiquant_case(5, Hkv, D, True)
+        kw = dict(antiq_scale=H.dev(a_s), antiq_offset=H.dev(a_o))
+        okw = dict(antiquant_scale=a_s.astype(np.float32), antiquant_offset=a_o.astype(np.float32))
+    scale = D ** -0.5
+    ahead = H.call_fusion(qd, kd, vd, td, l1d, idsd, seqd, Hq, Hkv, scale, bs, topk, out_dtype=torch.float32, **kw)
+    _abi.check(_abi.spfaSetSharedScoring(0), "spfaSetSharedScoring")
+    try:
+        one_by_one = H.call_fusion(qd, kd, vd, td, l1d, idsd, seqd, Hq, Hkv, scale, bs, topk, out_dtype=torch.float32, **kw)
+    finally:
+        _abi.spfaSetSharedScoring(1)
+    assert all(torch.equal(x, y) for x, y in zip(ahead[1:], one_by_one[1:]))
+    assert float((ahead[0] - one_by_one[0]).abs().max()) <= 2e-6 * float(one_by_one[0].abs().max())
+    want, wpos, wlen, wmax = ref.sparse_paged_fusion_attention(q, k, v, table, l1, ids, seq, Hq, Hkv, scale, bs, topk, 256, **okw)
+    out, pos, plen, pmax = ahead
+    assert np.array_equal(pos.cpu().numpy(), wpos)
+    assert np.array_equal(plen.cpu().numpy(), wlen)
+    assert np.array_equal(pmax.cpu().numpy(), wmax)
+    assert float(parity.rel_err(H.f32(out), want).max()) <= TOL
