@@ -66,6 +66,10 @@ thread_local int64_t g_page_size = 128;   // PAGESIZE of cent_select.cpp:17 / se
 thread_local const long long* g_act_seq_dev = nullptr;   // one-shot, consumed by the next attention plan
 thread_local int64_t g_act_seq_dev_n = 0;
 thread_local int g_token_positions = 0;      // one-shot: the next attention plan reads blockposition as token indices
+thread_local float* g_lse_out = nullptr;     // one-shot: the next attention plan also writes the rows' log-sum-exp there
+thread_local int64_t g_lse_out_n = 0;
+struct SharedPrefix { const void* k; const void* v; int64_t tokens, len; };
+thread_local SharedPrefix g_prefix{nullptr, nullptr, 0, 0};   // one-shot: consumed by the next attention plan
 thread_local void* g_debug_buf = nullptr;   // diagnostic stamp buffer (see spfaSetDebugBuffer)
 
 constexpr size_t kMaxLds = 160 * 1024;    // LDS per CU on gfx950
@@ -82,6 +86,17 @@ SelectionKnobs take_selection_knobs() {
     g_page_cap = 0;
     g_page_size = 128;
     return k;
+}
+
+// One-shot operands of the two attention ops that the aclnn signatures have no slot for (taken before anything can
+// fail, so a rejected call never leaves a device pointer armed for the next one).
+struct AttentionExtras { float* lse; int64_t lse_n; SharedPrefix prefix; };
+AttentionExtras take_attention_extras() {
+    const AttentionExtras x{g_lse_out, g_lse_out_n, g_prefix};
+    g_lse_out = nullptr;
+    g_lse_out_n = 0;
+    g_prefix = SharedPrefix{nullptr, nullptr, 0, 0};
+    return x;
 }
 
 int current_device_or_none() {
@@ -311,6 +326,20 @@ aclnnStatus spfaSetActualSeqLengthsDevice(const int64_t* dev, int64_t n) {
     return ACLNN_SUCCESS;
 }
 aclnnStatus spfaSetTokenPositions(int enable) { g_token_positions = enable ? 1 : 0; return ACLNN_SUCCESS; }
+aclnnStatus spfaSetSharedPrefix(const void* keyPrefix, const void* valuePrefix, int64_t prefixTokens, int64_t actualPrefixLen) {
+    if ((keyPrefix == nullptr) != (valuePrefix == nullptr))
+        return fail(ACLNN_ERR_PARAM_INVALID, "key and value shared prefix must be given together");
+    if (keyPrefix && (prefixTokens < 1 || actualPrefixLen < 0 || actualPrefixLen > prefixTokens))
+        return fail(ACLNN_ERR_PARAM_INVALID, "shared prefix of %lld tokens with actual length %lld", (long long)prefixTokens,
+                    (long long)actualPrefixLen);
+    g_prefix = keyPrefix ? SharedPrefix{keyPrefix, valuePrefix, prefixTokens, actualPrefixLen} : SharedPrefix{nullptr, nullptr, 0, 0};
+    return ACLNN_SUCCESS;
+}
+aclnnStatus spfaSetSoftmaxLseOut(float* deviceLse, int64_t n) {
+    g_lse_out = deviceLse;
+    g_lse_out_n = deviceLse ? n : 0;
+    return ACLNN_SUCCESS;
+}
 aclnnStatus spfaSetWorkspacePersistent(aclOpExecutor* e, int enable) {
     if (!e) return fail(ACLNN_ERR_PARAM_NULLPTR, "executor is NULL");
     if (enable && !e->repeatable) return fail(ACLNN_ERR_PARAM_INVALID, "only a repeatable executor can keep a workspace");
@@ -674,6 +703,38 @@ static aclnnStatus plan_extras(spfa::AttnParams& p, const aclTensor* query, cons
     return ACLNN_SUCCESS;
 }
 
+// The operands that arrive through one-shot setters instead of the aclnn argument list.
+static aclnnStatus plan_oneshot_extras(spfa::AttnParams& p, const AttentionExtras& x) {
+    if (x.lse) {
+        REQUIRE(x.lse_n >= (int64_t)p.B * p.Hq, "softmax LSE output has %lld values < batch %d * numHeads %d",
+                (long long)x.lse_n, p.B, p.Hq);
+        REQUIRE(((uintptr_t)x.lse & 3) == 0, "softmax LSE output must be 4-byte aligned device memory");
+        p.lse = x.lse;
+    }
+    if (x.prefix.k && x.prefix.len > 0) {
+        // …_tiling.cc: the prefix tensors have the KV dtype and layout with batch 1; here they are addressed with the
+        // cache's token stride, so only the distance between heads differs between the two layouts
+        REQUIRE(!p.token_mode, "a shared prefix is not supported with token-level positions");
+        REQUIRE(x.prefix.len <= 0x7fffffff / 2, "shared prefix of %lld tokens is too long", (long long)x.prefix.len);
+        REQUIRE((((uintptr_t)x.prefix.k | (uintptr_t)x.prefix.v) & 15) == 0, "shared prefix tensors must be 16-byte aligned");
+        const long long es = p.kv_dtype == spfa::kI8 ? 1 : 2;
+        const bool bsh = p.Hkv == 1 || p.head_stride == (long long)p.D * es;
+        p.prefix_k = x.prefix.k;
+        p.prefix_v = x.prefix.v;
+        p.prefix_head_stride = bsh ? (long long)p.D * es : x.prefix.tokens * p.D * es;
+        p.prefix_len = (int)x.prefix.len;
+        p.prefix_pages = (p.prefix_len + p.block_size - 1) / p.block_size;
+        REQUIRE((long long)p.max_entries + p.prefix_pages <= 4095, "page list of %d entries plus %d prefix runs exceeds 4095",
+                p.max_entries, p.prefix_pages);
+        p.max_entries += p.prefix_pages;
+        // pseShift / attenMask columns start with the prefix tokens (…Us2.h:2263-2266, 2283-2285)
+        const long long s_need = (long long)p.max_page * p.block_size + p.prefix_len;
+        REQUIRE(!p.pse || p.pse_s >= s_need, "pseShift S %lld is less than prefix + sMax = %lld", p.pse_s, s_need);
+        REQUIRE(!p.amask || p.amask_s >= s_need, "attenMask S %lld is less than prefix + sMax = %lld", p.amask_s, s_need);
+    }
+    return ACLNN_SUCCESS;
+}
+
 constexpr uint64_t kCounterBytes = 256;   // 8 work counters at the start of the workspace, zeroed per launch
 
 static size_t carve_lds(spfa::AttnParams& p, size_t nq) {
@@ -856,6 +917,7 @@ aclnnStatus aclnnSparsePagedAttentionGetWorkspaceSize(
     g_act_seq_dev_n = 0;
     const int token_positions = g_token_positions;
     g_token_positions = 0;
+    const AttentionExtras extras = take_attention_extras();
     REQUIRE_PTR(workspaceSize, "workspaceSize");
     REQUIRE_PTR(executor, "executor");
     REJECT_PRESENT(dequantScale1, "dequantScale1");   // int8 queries are not part of this path
@@ -912,6 +974,8 @@ aclnnStatus aclnnSparsePagedAttentionGetWorkspaceSize(
     }
     st = plan_extras(p, query, pseShift, attenMask, quantScale2, quantOffset2, attentionOut);
     if (st != ACLNN_SUCCESS) return bail(st);
+    st = plan_oneshot_extras(p, extras);
+    if (st != ACLNN_SUCCESS) return bail(st);
     st = plan_lds(p);
     if (st != ACLNN_SUCCESS) return bail(st);
     plan_workspace(e);
@@ -957,6 +1021,7 @@ aclnnStatus aclnnSparsePagedFusionAttentionGetWorkspaceSize(
     const aclTensor* max_page_position_length, const aclTensor* attentionOut, uint64_t* workspaceSize,
     aclOpExecutor** executor) {
     const SelectionKnobs knobs = take_selection_knobs();
+    const AttentionExtras extras = take_attention_extras();
     REQUIRE_PTR(workspaceSize, "workspaceSize");
     REQUIRE_PTR(executor, "executor");
     REJECT_PRESENT(dequantScale1, "dequantScale1");   // int8 queries are not part of this path
@@ -1012,6 +1077,8 @@ aclnnStatus aclnnSparsePagedFusionAttentionGetWorkspaceSize(
     }
     p.max_entries = max_page;   // the union of a group's lists never exceeds the logical page count
     st = plan_extras(p, query, pseShift, attenMask, quantScale2, quantOffset2, attentionOut);
+    if (st != ACLNN_SUCCESS) return bail(st);
+    st = plan_oneshot_extras(p, extras);
     if (st != ACLNN_SUCCESS) return bail(st);
     st = plan_lds(p);
     if (st != ACLNN_SUCCESS) return bail(st);

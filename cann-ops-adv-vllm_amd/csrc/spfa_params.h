@@ -102,6 +102,17 @@ struct AttnParams {
     const void* quant_offset2; // same shape and dtype as quant_scale2, or null
     int quant2_dtype;          // kF32 | kBF16
     int quant2_per_channel;    // 1: [Hq * D]
+    // Shared prefix (…Us2.h:1418-1439, 2263-2266): prefix_len tokens whose K / V rows every output row attends in front
+    // of its gathered pages, held once in tensors of their own with the cache's token stride — BSH [1, S, Hkv * D] or
+    // BNSD [1, Hkv, S, D].  They travel as leading page-list entries with phys = -1 - j (j-th run of block_size tokens).
+    const void* prefix_k;      // or null
+    const void* prefix_v;
+    long long prefix_head_stride;   // bytes between two heads' rows of one token (BSH) / between two heads (BNSD)
+    int prefix_len;            // attended prefix tokens
+    int prefix_pages;          // ceil(prefix_len / block_size) leading list entries
+    // softmax log-sum-exp of every output row (natural log, …Us2.h:3130-3159; -3.4e38 for a row without attended
+    // tokens, :1289-1300), or null
+    float* lse;                // [B, Hq]
     // mode 0
     // 1: block_position holds LOGICAL TOKEN indices (sentinel terminated; token t lives in row t % block_size of page
     // block_table[b][t / block_size]) and actual_seq_lengths counts tokens, the token-level variant sketched in the

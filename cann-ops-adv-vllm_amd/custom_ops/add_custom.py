@@ -12,6 +12,12 @@ the C-ABI that the very next phase 1 consumes):
   max_pages_cap clip page_position_length to pageLen // 8 (cent_select.cpp:218,410-414)
   max_page_num  slots per page_position row (reference: 256, add_custom.cpp:958,987)
   page_size     page size of cent_select / select_position (reference: 128, cent_select.cpp:17)
+The two attention ops also take the operands of the reference KERNEL that its aclnn signatures for the sparse ops leave
+out (sparse_paged_fusion_attention_split_Bbn2s2_Us2.h:1418-1439, 3130-3159):
+  softmax_lse               float32 tensor of B * num_heads values, filled with every row's softmax log-sum-exp
+  key_shared_prefix, value_shared_prefix, actual_shared_prefix_len
+                            K / V rows of a prefix that every row attends in front of its pages: [1, S, Hkv * D] for a
+                            [blocks, block_size, Hkv * D] cache, [1, Hkv, S, D] for a [blocks, Hkv, block_size, D] cache
 """
 from __future__ import annotations
 
@@ -116,6 +122,36 @@ def _seq_lengths_arg(actual_seq_lengths, device):
     return _abi.to_int_array(actual_seq_lengths), None
 
 
+def _set_attention_extras(softmax_lse, key_shared_prefix, value_shared_prefix, actual_shared_prefix_len, key,
+                          num_key_value_heads, block_size):
+    """Arm the one-shot operands that the aclnn signatures have no slot for; call right in front of phase 1."""
+    if softmax_lse is not None:
+        if softmax_lse.dtype != torch.float32 or not softmax_lse.is_contiguous() or not softmax_lse.is_cuda:
+            raise _abi.AclError("softmax_lse must be a contiguous float32 GPU tensor")
+        _abi.check(_abi.spfaSetSoftmaxLseOut(softmax_lse.data_ptr(), softmax_lse.numel()), "spfaSetSoftmaxLseOut")
+    if key_shared_prefix is not None or value_shared_prefix is not None:
+        kp, vp = key_shared_prefix, value_shared_prefix
+        if kp is None or vp is None or kp.shape != vp.shape or kp.dtype != key.dtype or vp.dtype != key.dtype:
+            raise _abi.AclError("key / value shared prefix must come together, equal in shape, in the KV cache's dtype")
+        if not (kp.is_cuda and vp.is_cuda and kp.is_contiguous() and vp.is_contiguous()) or kp.shape[0] != 1:
+            raise _abi.AclError("shared prefix tensors must be contiguous GPU tensors with batch 1")
+        # the cache is [blocks, bs, Hkv * D], [blocks, bs, Hkv, D] (both token-major) or [blocks, Hkv, bs, D]; the C side
+        # tells the last two apart by dims[1] == block_size first, so do the same here
+        bnsd = key.dim() == 4 and not (key.shape[1] == block_size and key.shape[2] == num_key_value_heads)
+        tokens = kp.shape[2] if (bnsd and kp.dim() == 4) else kp.shape[1]
+        row = key.shape[-1] * (num_key_value_heads if key.dim() == 4 else 1)   # elements of one token over all kv heads
+        if kp.numel() != tokens * row:
+            raise _abi.AclError("shared prefix must be [1, S, Hkv * D] / [1, S, Hkv, D] (token-major cache) or "
+                                "[1, Hkv, S, D] ([blocks, Hkv, block_size, D] cache)")
+        n = tokens if actual_shared_prefix_len is None else int(actual_shared_prefix_len)
+        _abi.check(_abi.spfaSetSharedPrefix(kp.data_ptr(), vp.data_ptr(), int(tokens), n), "spfaSetSharedPrefix")
+
+
+def _clear_attention_extras():
+    _abi.spfaSetSoftmaxLseOut(None, 0)
+    _abi.spfaSetSharedPrefix(None, None, 0, 0)
+
+
 def _default_out_dtype(query, quant_scale2):
     """The output has the query's dtype unless an output quantisation scale asks for int8
     (sparse_paged_fusion_attention_tiling.cc:569-605)."""
@@ -131,7 +167,10 @@ def sparse_paged_attention(query: torch.Tensor, key: torch.Tensor, value: torch.
                            antiquant_offset: torch.Tensor, blocktable: torch.Tensor, kv_padding_size: torch.Tensor,
                            blockposition: torch.Tensor, num_heads: int, scale_value: float, input_layout: str,
                            num_key_value_heads: int, block_size: int, inner_precise: int,
-                           *, out_dtype: Optional[torch.dtype] = None, token_level: bool = False) -> torch.Tensor:
+                           *, out_dtype: Optional[torch.dtype] = None, token_level: bool = False,
+                           softmax_lse: Optional[torch.Tensor] = None, key_shared_prefix: Optional[torch.Tensor] = None,
+                           value_shared_prefix: Optional[torch.Tensor] = None,
+                           actual_shared_prefix_len: Optional[int] = None) -> torch.Tensor:
     """Decode attention over the pages listed in blockposition (add_custom.py:41-75; binding
     sparse_paged_attention_impl_npu wraps key/value into one-tensor lists and returns a tensor shaped
     like query).  out_dtype=torch.float32 (extra) returns the un-rounded result.
@@ -162,6 +201,8 @@ def sparse_paged_attention(query: torch.Tensor, key: torch.Tensor, value: torch.
         seq_arr, dev_lengths = _seq_lengths_arg(actual_seq_lengths, dev)
         arrays = [seq_arr]
         _abi.check(_abi.spfaSetTokenPositions(1 if token_level else 0), "spfaSetTokenPositions")
+        _set_attention_extras(softmax_lse, key_shared_prefix, value_shared_prefix, actual_shared_prefix_len, key,
+                              int(num_key_value_heads), int(block_size))
         args = tens[:1] + lists + opt + [seq_arr] + quant + [
             int(num_heads), float(scale_value), str(input_layout).encode(), int(num_key_value_heads), int(block_size),
             int(inner_precise), tens[1]]
@@ -170,6 +211,7 @@ def sparse_paged_attention(query: torch.Tensor, key: torch.Tensor, value: torch.
     finally:
         _abi.spfaSetActualSeqLengthsDevice(None, 0)
         _abi.spfaSetTokenPositions(0)
+        _clear_attention_extras()
         _destroy(tens + opt + quant, lists, arrays)
     if dev_lengths is not None:
         dev_lengths.record_stream(torch.cuda.current_stream(dev))
@@ -187,7 +229,11 @@ def sparse_paged_fusion_attention(query: torch.Tensor, key: torch.Tensor, value:
                                   page_position_length: torch.Tensor, max_page_position_length: torch.Tensor,
                                   num_heads: int, scale_value: float, input_layout: str, num_key_value_heads: int,
                                   block_size: int, inner_precise: int, *, k: int = 64, sink_recent: bool = False,
-                                  max_pages_cap: bool = False, out_dtype: Optional[torch.dtype] = None
+                                  max_pages_cap: bool = False, out_dtype: Optional[torch.dtype] = None,
+                                  softmax_lse: Optional[torch.Tensor] = None,
+                                  key_shared_prefix: Optional[torch.Tensor] = None,
+                                  value_shared_prefix: Optional[torch.Tensor] = None,
+                                  actual_shared_prefix_len: Optional[int] = None
                                   ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """CentSelect + sparse paged attention in one kernel launch (add_custom.py:96-135).  Returns
     (attention_out, block_position, max_page_position_length) — the 3-tuple of the registered schema
@@ -209,9 +255,12 @@ def sparse_paged_fusion_attention(query: torch.Tensor, key: torch.Tensor, value:
         int(inner_precise)] + outs
     try:
         _set_knobs(k, sink_recent, max_pages_cap)
+        _set_attention_extras(softmax_lse, key_shared_prefix, value_shared_prefix, actual_shared_prefix_len, key,
+                              int(num_key_value_heads), int(block_size))
         _abi.run(_abi.aclnnSparsePagedFusionAttentionGetWorkspaceSize, _abi.aclnnSparsePagedFusionAttention, args,
                  dev, "aclnnSparsePagedFusionAttention")
     finally:
+        _clear_attention_extras()
         _destroy(tens + mid + rest + outs, [kl, vl])
     return out, block_position, max_page_position_length
 

@@ -128,6 +128,22 @@ SPFA_API aclnnStatus spfaSetActualSeqLengthsDevice(const int64_t* deviceLengths,
  * token-level variant the reference sketches in tests/ifa_v5_case_tkp.py:53-54.  Head dims 64 and 128; pseShift /
  * attenMask are refused; every q head is streamed as its own pass. */
 SPFA_API aclnnStatus spfaSetTokenPositions(int enable);
+/* One-shot: the next aclnnSparsePagedAttentionGetWorkspaceSize / aclnnSparsePagedFusionAttentionGetWorkspaceSize on
+ * this thread also writes the softmax log-sum-exp of every output row, ln(sum_t exp(score_t)) as float32, to this
+ * DEVICE array of n >= B * numHeads values laid out [B, numHeads] — the softmaxLse output of the reference kernel
+ * (sparse_paged_fusion_attention_split_Bbn2s2_Us2.h:3130-3159; a row that attends nothing gets -3.4e38, :1289-1300),
+ * for which the aclnn signatures of the two sparse ops have no operand.  NULL disarms. */
+SPFA_API aclnnStatus spfaSetSoftmaxLseOut(float* deviceLse, int64_t n);
+/* One-shot: the next phase 1 of the two sparse attention ops on this thread lets every output row attend, in front of
+ * its gathered pages, the first actualPrefixLen tokens of a prefix shared by the whole batch — the keySharedPrefix /
+ * valueSharedPrefix / actualSharedPrefixLen operands of the kernel the sparse ops were derived from
+ * (sparse_paged_fusion_attention_split_Bbn2s2_Us2.h:1418-1439; their aclnn signatures carry no such operands).
+ * The two DEVICE tensors have the KV cache's dtype and layout with batch 1: [1, prefixTokens, Hkv * D] for a
+ * [blocks, blockSize, Hkv * D] cache, [1, Hkv, prefixTokens, D] for a [blocks, Hkv, blockSize, D] cache; int8
+ * prefixes use the op's antiquant parameters.  pseShift / attenMask columns then start with the prefix tokens
+ * (:2263-2266).  Not available with token-level positions.  NULL pointers disarm. */
+SPFA_API aclnnStatus spfaSetSharedPrefix(const void* keyPrefix, const void* valuePrefix, int64_t prefixTokens,
+                                         int64_t actualPrefixLen);
 /* A launch of the two attention ops starts with a small kernel that zeroes the counters at the head of the workspace;
  * the op's kernel leaves them zeroed again when it ends.  enable = 1 on a repeatable executor of
  * SparsePagedFusionAttention promises that nothing but this executor's launches writes the workspace between

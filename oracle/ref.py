@@ -191,7 +191,9 @@ def sparse_paged_attention(q, key_cache, value_cache, block_table, block_positio
                            antiquant_scale=None, antiquant_offset=None,
                            token_limit=None, p_round: str | None = None,
                            exact: bool = True, pse_shift=None, atten_mask=None,
-                           quant_scale2=None, quant_offset2=None, token_level: bool = False) -> np.ndarray:
+                           quant_scale2=None, quant_offset2=None, token_level: bool = False,
+                           key_shared_prefix=None, value_shared_prefix=None, shared_prefix_len=None,
+                           return_lse: bool = False):
     """Decode attention over a virtual sequence of selected pages.  Returns fp32 [B,Hq,D].
 
     Virtual token t of batch b / head row r lives in virtual page j = t // bs; its
@@ -223,6 +225,15 @@ def sparse_paged_attention(q, key_cache, value_cache, block_table, block_positio
     reference's tests/ifa_v5_case_tkp.py:53-54): entry j < actual_seq_lengths[b] before the first
     0x7fffffff is token t, row t % bs of page block_table[b, t // bs].
 
+    key_shared_prefix / value_shared_prefix ([1, S, Hkv * D] | [1, S, Hkv, D] for a BSH cache, [1, Hkv, S, D] for
+    BNSD; the KV dtype, int8 with the same antiquant parameters): every row attends the first shared_prefix_len
+    (default S) prefix tokens in front of its gathered pages; pse_shift / atten_mask columns then start with the
+    prefix tokens (…Us2.h:1418-1439, 2263-2266, 2283-2285).
+
+    return_lse=True: also returns the rows' softmax log-sum-exp [B, Hq] float32, ln(sum_t exp(score_t)) with the
+    scores as the formula has them — for int8 KV including the key offset the kernel drops from its products and
+    adds back here (…Us2.h:2651-2659, 3130-3159); -3.4e38 for a row that attends nothing (:1289-1300).  exact mode.
+
     quant_scale2 / quant_offset2 (scalar or [Hq * D]): int8 output,
     out * scale2 + offset2 in fp32, cast to f16 and then to int8, both with ties away from
     zero (…Us2.h:4016-4111); the result is returned as float32 holding the int8 values.
@@ -249,7 +260,18 @@ def sparse_paged_attention(q, key_cache, value_cache, block_table, block_positio
     amask = None if atten_mask is None else np.asarray(atten_mask).reshape(B, -1)
     assert (pse is None and amask is None) or exact, "pse_shift / atten_mask: exact mode only"
     out = np.zeros((B, Hq, D), dtype=np.float32)
+    lse = np.full((B, Hq), np.float32(-3.40e38), dtype=np.float32)
+    assert not return_lse or exact, "return_lse: exact mode only"
     facc = np.float64 if exact else np.float32
+    n_pre = 0
+    if key_shared_prefix is not None:
+        kp, vp = np.asarray(key_shared_prefix), np.asarray(value_shared_prefix)
+        if kv_layout == "BSH":
+            kp, vp = kp.reshape(-1, Hkv, D), vp.reshape(-1, Hkv, D)                  # [S, Hkv, D]
+        else:
+            kp, vp = kp.reshape(Hkv, -1, D).transpose(1, 0, 2), vp.reshape(Hkv, -1, D).transpose(1, 0, 2)
+        n_pre = kp.shape[0] if shared_prefix_len is None else int(shared_prefix_len)
+        assert 0 <= n_pre <= kp.shape[0] and not token_level
     for b in range(B):
         for h in range(Hq):
             n2 = h // G
@@ -265,6 +287,10 @@ def sparse_paged_attention(q, key_cache, value_cache, block_table, block_positio
             if quant:
                 qv = qv * a_s[0, n2].astype(facc)
             ks, vs, cols = [], [], []
+            if n_pre:
+                ks.append(kp[:n_pre, n2])
+                vs.append(vp[:n_pre, n2])
+                cols.append(np.arange(n_pre))
             if token_level:
                 n_tok = P if actual_seq_lengths is None else int(actual_seq_lengths[b])
                 n_ent = min(int(sent[0]) if sent.size else P, max(0, n_tok))
@@ -292,7 +318,7 @@ def sparse_paged_attention(q, key_cache, value_cache, block_table, block_positio
                     continue
                 ks.append(_kv_rows(key_cache, blk, n2, kv_layout, Hkv, D)[:valid])
                 vs.append(_kv_rows(value_cache, blk, n2, kv_layout, Hkv, D)[:valid])
-                cols.append(j * block_size + np.arange(valid))
+                cols.append(n_pre + j * block_size + np.arange(valid))
             if not ks:
                 continue
             if exact:
@@ -306,6 +332,10 @@ def sparse_paged_attention(q, key_cache, value_cache, block_table, block_positio
                     s = np.where(amask[b, col] != 0, np.float64(-1e12), s)
                 p_ = np.exp(s - s.max())
                 o = (p_ @ V) / p_.sum()
+                row_const = 0.0
+                if quant and a_o is not None:   # the key offset's share of every score of the row
+                    row_const = float(scale) * float((qv * a_o[0, n2].astype(np.float64)).sum())
+                lse[b, h] = np.float32(np.log(p_.sum()) + s.max() + row_const)
             else:
                 m = np.float32(-2e38)
                 l = np.float32(0)
@@ -330,7 +360,7 @@ def sparse_paged_attention(q, key_cache, value_cache, block_table, block_positio
             out[b, h] = o.astype(np.float32)
     if quant_scale2 is not None:
         out = post_quant(out, quant_scale2, quant_offset2)
-    return out
+    return (out, lse) if return_lse else out
 
 
 def _round_half_away(x: np.ndarray) -> np.ndarray:
@@ -369,7 +399,9 @@ def sparse_paged_fusion_attention(q, key_cache, value_cache, block_table, l1_cen
                                   sink_recent: bool = False, max_pages_cap: bool = False,
                                   kv_layout: str = "BSH", antiquant_scale=None,
                                   antiquant_offset=None, p_round=None, exact: bool = True,
-                                  pse_shift=None, atten_mask=None, quant_scale2=None, quant_offset2=None):
+                                  pse_shift=None, atten_mask=None, quant_scale2=None, quant_offset2=None,
+                                  key_shared_prefix=None, value_shared_prefix=None, shared_prefix_len=None,
+                                  return_lse: bool = False):
     """cent_select then attention over each q head's own page list
     (sparse_paged_fusion_attention.cpp:56-76; attention runs with
     actualSeqLengths := max_page_position_length and blockPosition := the rows just
@@ -378,7 +410,7 @@ def sparse_paged_fusion_attention(q, key_cache, value_cache, block_table, l1_cen
     reference whenever total_seq_len is a multiple of block_size, as in all its tests).
 
     Returns (attention_out fp32 [B,Hq,D], page_position, page_position_length[B,Hq,8],
-             max_page_position_length [B,8]).
+             max_page_position_length [B,8]); with return_lse=True attention_out is the pair (out, lse).
     """
     pos, len8, max8, _ = cent_select(q, l1_cent, block_ids, block_table, total_seq_len, k,
                                      block_size, max_page_num, sink_recent, max_pages_cap)
@@ -392,7 +424,9 @@ def sparse_paged_fusion_attention(q, key_cache, value_cache, block_table, l1_cen
                                  antiquant_scale, antiquant_offset,
                                  token_limit=np.asarray(total_seq_len), p_round=p_round, exact=exact,
                                  pse_shift=pse_shift, atten_mask=atten_mask, quant_scale2=quant_scale2,
-                                 quant_offset2=quant_offset2)
+                                 quant_offset2=quant_offset2, key_shared_prefix=key_shared_prefix,
+                                 value_shared_prefix=value_shared_prefix, shared_prefix_len=shared_prefix_len,
+                                 return_lse=return_lse)
     return out, pos, len8, max8
 
 
