@@ -70,6 +70,7 @@ thread_local float* g_lse_out = nullptr;     // one-shot: the next attention pla
 thread_local int64_t g_lse_out_n = 0;
 struct SharedPrefix { const void* k; const void* v; int64_t tokens, len; };
 thread_local SharedPrefix g_prefix{nullptr, nullptr, 0, 0};   // one-shot: consumed by the next attention plan
+thread_local int g_antiq_mode = 0;          // one-shot: 0 per channel / per tensor, 1 per token
 thread_local void* g_debug_buf = nullptr;   // diagnostic stamp buffer (see spfaSetDebugBuffer)
 
 constexpr size_t kMaxLds = 160 * 1024;    // LDS per CU on gfx950
@@ -90,9 +91,10 @@ SelectionKnobs take_selection_knobs() {
 
 // One-shot operands of the two attention ops that the aclnn signatures have no slot for (taken before anything can
 // fail, so a rejected call never leaves a device pointer armed for the next one).
-struct AttentionExtras { float* lse; int64_t lse_n; SharedPrefix prefix; };
+struct AttentionExtras { float* lse; int64_t lse_n; SharedPrefix prefix; int antiq_mode; };
 AttentionExtras take_attention_extras() {
-    const AttentionExtras x{g_lse_out, g_lse_out_n, g_prefix};
+    const AttentionExtras x{g_lse_out, g_lse_out_n, g_prefix, g_antiq_mode};
+    g_antiq_mode = 0;
     g_lse_out = nullptr;
     g_lse_out_n = 0;
     g_prefix = SharedPrefix{nullptr, nullptr, 0, 0};
@@ -335,6 +337,12 @@ aclnnStatus spfaSetSharedPrefix(const void* keyPrefix, const void* valuePrefix, 
     g_prefix = keyPrefix ? SharedPrefix{keyPrefix, valuePrefix, prefixTokens, actualPrefixLen} : SharedPrefix{nullptr, nullptr, 0, 0};
     return ACLNN_SUCCESS;
 }
+aclnnStatus spfaSetAntiquantMode(int64_t mode) {
+    if (mode != 0 && mode != 1)
+        return fail(ACLNN_ERR_PARAM_INVALID, "antiquant mode %lld: 0 (per channel / per tensor) or 1 (per token)", (long long)mode);
+    g_antiq_mode = (int)mode;
+    return ACLNN_SUCCESS;
+}
 aclnnStatus spfaSetSoftmaxLseOut(float* deviceLse, int64_t n) {
     g_lse_out = deviceLse;
     g_lse_out_n = deviceLse ? n : 0;
@@ -523,7 +531,7 @@ static aclnnStatus plan_attention(spfa::AttnParams& p, const aclTensor* query, c
                                   const aclTensorList* value, const aclTensor* antiquantScale,
                                   const aclTensor* antiquantOffset, const aclTensor* blocktable, int64_t numHeads,
                                   double scaleValue, const char* inputLayout, int64_t numKeyValueHeads,
-                                  int64_t blockSize, const aclTensor* attentionOut, int batch_limit) {
+                                  int64_t blockSize, const aclTensor* attentionOut, int batch_limit, int antiq_mode) {
     REQUIRE_PTR(query, "query");
     REQUIRE(query->dtype == ACL_FLOAT16 || query->dtype == ACL_BF16, "query must be float16 or bfloat16");
     REQUIRE(is_contiguous(query), "query must be contiguous");
@@ -591,7 +599,21 @@ static aclnnStatus plan_attention(spfa::AttnParams& p, const aclTensor* query, c
             "head dim %d with %d-byte KV elements is not supported (row bytes must be 64, 128, 256, 512 or 1024)", D, es);
     REQUIRE(kd[0] > 0 && kd[0] <= 0x7fffffff, "KV cache has no blocks");
 
-    if (quant) {
+    REQUIRE(antiq_mode == 0 || quant, "a per-token antiquant mode needs an int8 KV cache");
+    if (quant && antiq_mode == 1) {
+        // per token (…_tiling.cc:733-765, …Us2.h:2039-2043): float32 [2, B, S], key parameters first; S is checked once
+        // the table width is known
+        REQUIRE(!absent(antiquantScale), "int8 KV cache needs antiquantScale");
+        REQUIRE(antiquantScale->dtype == ACL_FLOAT && antiquantScale->dims.size() == 3 && antiquantScale->dims[0] == 2 &&
+                    is_contiguous(antiquantScale) && antiquantScale->data,
+                "per-token antiquantScale must be a contiguous float32 [2, B, S] tensor (…_tiling.cc:733-765)");
+        if (!absent(antiquantOffset))
+            REQUIRE(antiquantOffset->dtype == ACL_FLOAT && antiquantOffset->dims == antiquantScale->dims &&
+                        is_contiguous(antiquantOffset) && antiquantOffset->data,
+                    "per-token antiquantOffset must have antiquantScale's shape and dtype");
+        p.antiq_per_token = 1;
+        p.antiq_s = antiquantScale->dims[2];
+    } else if (quant) {
         REQUIRE(!absent(antiquantScale), "int8 KV cache needs antiquantScale");
         // [2]: one key and one value parameter for the whole tensor (…_tiling.cc:785-793; the value parameter is
         // element 1, …Us2.h:2036-2038), else per channel
@@ -618,6 +640,13 @@ static aclnnStatus plan_attention(spfa::AttnParams& p, const aclTensor* query, c
         B = batch_limit;
     }
     REQUIRE(blocktable->dims[0] >= B, "blocktable has %lld rows < batch %d", (long long)blocktable->dims[0], B);
+    if (p.antiq_per_token) {
+        REQUIRE(antiquantScale->dims[1] == B, "per-token antiquantScale holds %lld batches, the op %d (…_tiling.cc:740)",
+                (long long)antiquantScale->dims[1], B);
+        REQUIRE(p.antiq_s >= blocktable->dims[1] * blockSize,
+                "per-token antiquant S %lld is less than sMax %lld (blocktable columns * blockSize, …_tiling.cc:745)",
+                p.antiq_s, (long long)(blocktable->dims[1] * blockSize));
+    }
 
     p.q = data_ptr(query);
     p.out = data_ptr(attentionOut);
@@ -711,6 +740,7 @@ static aclnnStatus plan_oneshot_extras(spfa::AttnParams& p, const AttentionExtra
         REQUIRE(((uintptr_t)x.lse & 3) == 0, "softmax LSE output must be 4-byte aligned device memory");
         p.lse = x.lse;
     }
+    REQUIRE(!(p.antiq_per_token && p.token_mode), "per-token antiquant parameters are not supported with token-level positions");
     if (x.prefix.k && x.prefix.len > 0) {
         // …_tiling.cc: the prefix tensors have the KV dtype and layout with batch 1; here they are addressed with the
         // cache's token stride, so only the distance between heads differs between the two layouts
@@ -731,6 +761,8 @@ static aclnnStatus plan_oneshot_extras(spfa::AttnParams& p, const AttentionExtra
         const long long s_need = (long long)p.max_page * p.block_size + p.prefix_len;
         REQUIRE(!p.pse || p.pse_s >= s_need, "pseShift S %lld is less than prefix + sMax = %lld", p.pse_s, s_need);
         REQUIRE(!p.amask || p.amask_s >= s_need, "attenMask S %lld is less than prefix + sMax = %lld", p.amask_s, s_need);
+        REQUIRE(!p.antiq_per_token || p.antiq_s >= s_need, "per-token antiquant S %lld is less than prefix + sMax = %lld",
+                p.antiq_s, s_need);
     }
     return ACLNN_SUCCESS;
 }
@@ -768,8 +800,10 @@ static size_t carve_lds(spfa::AttnParams& p, size_t nq) {
 
 static aclnnStatus plan_lds(spfa::AttnParams& p) {
     const bool per_head = (p.mode == 0 && p.pos_rows == p.Hq && p.G > 1);
-    // pseShift / attenMask index the columns of ONE head's list: every q head runs as its own pass
-    int nq = (per_head || p.pse || p.amask || p.token_mode) ? 1 : spfa::attention_rows_per_pass(p.G, p.kv_dtype, p.D);
+    // pseShift / attenMask / per-token antiquant parameters index the columns of ONE head's list: every q head runs
+    // as its own pass
+    int nq = (per_head || p.pse || p.amask || p.token_mode || p.antiq_per_token) ? 1
+                                                                                  : spfa::attention_rows_per_pass(p.G, p.kv_dtype, p.D);
     size_t need = carve_lds(p, (size_t)nq);
     // a large group with many clusters: fewer q heads per pass (more passes over the pages) until the keys fit
     while (need > kMaxLds && nq > 2 && spfa::attention_uses_mfma(nq, p.kv_dtype, p.D)) {
@@ -930,7 +964,7 @@ aclnnStatus aclnnSparsePagedAttentionGetWorkspaceSize(
     spfa::AttnParams& p = e->attn;
     p.mode = 0;
     aclnnStatus st = plan_attention(p, query, key, value, antiquantScale, antiquantOffset, blocktable, numHeads,
-                                    scaleValue, inputLayout, numKeyValueHeads, blockSize, attentionOut, -1);
+                                    scaleValue, inputLayout, numKeyValueHeads, blockSize, attentionOut, -1, extras.antiq_mode);
     auto bail = [&](aclnnStatus s) { delete e; return s; };
     if (st != ACLNN_SUCCESS) return bail(st);
     st = check_tensor(blockposition, "blockposition", 3, ACL_INT32);
@@ -1039,7 +1073,7 @@ aclnnStatus aclnnSparsePagedFusionAttentionGetWorkspaceSize(
     p.mode = 1;
     auto bail = [&](aclnnStatus s) { delete e; return s; };
     aclnnStatus st = plan_attention(p, query, key, value, antiquantScale, antiquantOffset, blocktable, numHeads,
-                                    scaleValue, inputLayout, numKeyValueHeads, blockSize, attentionOut, B);
+                                    scaleValue, inputLayout, numKeyValueHeads, blockSize, attentionOut, B, extras.antiq_mode);
     if (st != ACLNN_SUCCESS) return bail(st);
     if (p.Hkv != Hkv || p.D != D)
         return bail(fail(ACLNN_ERR_PARAM_INVALID, "l1_cent [%d, %d, %d] does not match numKeyValueHeads %d / head dim %d",

@@ -132,9 +132,9 @@ hipError_t ensure_lds_limit(const void* kern, int* table, size_t bytes) {
 
 // cap_out != nullptr (phase 1): set the LDS limit, ask the runtime how many workgroups fit a CU, report the resident
 // grid.  Otherwise (phase 2): launch; with p.grid_cap from phase 1 this is nothing but the launch itself.
-template <typename KVT, int NQ, int LPT, bool MFMA, bool TOK = false>
+template <typename KVT, int NQ, int LPT, bool MFMA, int VAR = 0>
 hipError_t launch_attn_one(const AttnParams& p, hipStream_t s, long long* cap_out) {
-    auto kern = attn_kernel<KVT, NQ, LPT, MFMA, TOK>;
+    auto kern = attn_kernel<KVT, NQ, LPT, MFMA, VAR>;
     static int lds_limit[kMaxDevices];
     long long cap = p.grid_cap;
     if (cap_out || cap <= 0) {
@@ -301,17 +301,27 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t s, long long* cap_o
         if (nq != 1 || p.mode != 0) return hipErrorInvalidValue;
         switch (p.kv_dtype) {
             case kF16:
-                if (lpt == 16) return launch_attn_one<_Float16, 1, 16, false, true>(p, s, cap_out);
-                if (lpt == 8) return launch_attn_one<_Float16, 1, 8, false, true>(p, s, cap_out);
+                if (lpt == 16) return launch_attn_one<_Float16, 1, 16, false, 1>(p, s, cap_out);
+                if (lpt == 8) return launch_attn_one<_Float16, 1, 8, false, 1>(p, s, cap_out);
                 break;
             case kBF16:
-                if (lpt == 16) return launch_attn_one<__bf16, 1, 16, false, true>(p, s, cap_out);
-                if (lpt == 8) return launch_attn_one<__bf16, 1, 8, false, true>(p, s, cap_out);
+                if (lpt == 16) return launch_attn_one<__bf16, 1, 16, false, 1>(p, s, cap_out);
+                if (lpt == 8) return launch_attn_one<__bf16, 1, 8, false, 1>(p, s, cap_out);
                 break;
             case kI8:
-                if (lpt == 8) return launch_attn_one<int8_t, 1, 8, false, true>(p, s, cap_out);
-                if (lpt == 4) return launch_attn_one<int8_t, 1, 4, false, true>(p, s, cap_out);
+                if (lpt == 8) return launch_attn_one<int8_t, 1, 8, false, 1>(p, s, cap_out);
+                if (lpt == 4) return launch_attn_one<int8_t, 1, 4, false, 1>(p, s, cap_out);
                 break;
+        }
+        return hipErrorInvalidValue;
+    }
+    if (p.antiq_per_token) {   // int8 KV with per-token parameters: one q head per pass
+        if (nq != 1 || p.kv_dtype != kI8) return hipErrorInvalidValue;
+        switch (lpt) {
+            case 4: return launch_attn_one<int8_t, 1, 4, false, 2>(p, s, cap_out);
+            case 8: return launch_attn_one<int8_t, 1, 8, false, 2>(p, s, cap_out);
+            case 16: return launch_attn_one<int8_t, 1, 16, false, 2>(p, s, cap_out);
+            case 32: return launch_attn_one<int8_t, 1, 32, false, 2>(p, s, cap_out);
         }
         return hipErrorInvalidValue;
     }

@@ -90,6 +90,11 @@ struct AttnParams {
     const void* antiq_scale;   // [2, Hkv*D] in q dtype, or null
     const void* antiq_offset;  // [2, Hkv*D] in q dtype, or null
     int antiq_per_tensor;      // 1: antiq_scale / antiq_offset are [2] (one key and one value parameter)
+    // 1: per-token parameters (…Us2.h:2039-2041, 3711-3822): antiq_scale / antiq_offset are float32 [2, B, antiq_s], one
+    // key and one value parameter per column of the gathered sequence (the columns of pse / amask); every q head runs
+    // as a pass of its own
+    int antiq_per_token;
+    long long antiq_s;
     // Additive score bias and boolean mask over the columns of the gathered sequence (column = list slot * block_size +
     // token in page), …Us2.h:3366-3404.  Either one makes every q head run as a pass of its own.
     const void* pse;           // [pse_b, Hq, 1, pse_s] in q dtype, or null

@@ -60,6 +60,7 @@ spfaSetSharedScoring = _sig("spfaSetSharedScoring", c_int, [c_int])
 spfaSetPageSize = _sig("spfaSetPageSize", c_int, [c_int64])
 spfaSetActualSeqLengthsDevice = _sig("spfaSetActualSeqLengthsDevice", c_int, [c_void_p, c_int64])
 spfaSetTokenPositions = _sig("spfaSetTokenPositions", c_int, [c_int])
+spfaSetAntiquantMode = _sig("spfaSetAntiquantMode", c_int, [c_int64])
 spfaSetSoftmaxLseOut = _sig("spfaSetSoftmaxLseOut", c_int, [c_void_p, c_int64])
 spfaSetSharedPrefix = _sig("spfaSetSharedPrefix", c_int, [c_void_p, c_void_p, c_int64, c_int64])
 spfaSetWorkspacePersistent = _sig("spfaSetWorkspacePersistent", c_int, [T, c_int])

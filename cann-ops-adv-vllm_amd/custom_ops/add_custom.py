@@ -18,6 +18,8 @@ out (sparse_paged_fusion_attention_split_Bbn2s2_Us2.h:1418-1439, 3130-3159):
   key_shared_prefix, value_shared_prefix, actual_shared_prefix_len
                             K / V rows of a prefix that every row attends in front of its pages: [1, S, Hkv * D] for a
                             [blocks, block_size, Hkv * D] cache, [1, Hkv, S, D] for a [blocks, Hkv, block_size, D] cache
+  antiquant_mode            0: antiquant_scale / antiquant_offset per channel [2, Hkv, D] or per tensor [2] (query dtype);
+                            1: per token, float32 [2, B, S] over the columns of the gathered sequence
 """
 from __future__ import annotations
 
@@ -123,8 +125,9 @@ def _seq_lengths_arg(actual_seq_lengths, device):
 
 
 def _set_attention_extras(softmax_lse, key_shared_prefix, value_shared_prefix, actual_shared_prefix_len, key,
-                          num_key_value_heads, block_size):
+                          num_key_value_heads, block_size, antiquant_mode=0):
     """Arm the one-shot operands that the aclnn signatures have no slot for; call right in front of phase 1."""
+    _abi.check(_abi.spfaSetAntiquantMode(int(antiquant_mode)), "spfaSetAntiquantMode")
     if softmax_lse is not None:
         if softmax_lse.dtype != torch.float32 or not softmax_lse.is_contiguous() or not softmax_lse.is_cuda:
             raise _abi.AclError("softmax_lse must be a contiguous float32 GPU tensor")
@@ -148,6 +151,7 @@ def _set_attention_extras(softmax_lse, key_shared_prefix, value_shared_prefix, a
 
 
 def _clear_attention_extras():
+    _abi.spfaSetAntiquantMode(0)
     _abi.spfaSetSoftmaxLseOut(None, 0)
     _abi.spfaSetSharedPrefix(None, None, 0, 0)
 
@@ -170,7 +174,7 @@ def sparse_paged_attention(query: torch.Tensor, key: torch.Tensor, value: torch.
                            *, out_dtype: Optional[torch.dtype] = None, token_level: bool = False,
                            softmax_lse: Optional[torch.Tensor] = None, key_shared_prefix: Optional[torch.Tensor] = None,
                            value_shared_prefix: Optional[torch.Tensor] = None,
-                           actual_shared_prefix_len: Optional[int] = None) -> torch.Tensor:
+                           actual_shared_prefix_len: Optional[int] = None, antiquant_mode: int = 0) -> torch.Tensor:
     """Decode attention over the pages listed in blockposition (add_custom.py:41-75; binding
     sparse_paged_attention_impl_npu wraps key/value into one-tensor lists and returns a tensor shaped
     like query).  out_dtype=torch.float32 (extra) returns the un-rounded result.
@@ -202,7 +206,7 @@ def sparse_paged_attention(query: torch.Tensor, key: torch.Tensor, value: torch.
         arrays = [seq_arr]
         _abi.check(_abi.spfaSetTokenPositions(1 if token_level else 0), "spfaSetTokenPositions")
         _set_attention_extras(softmax_lse, key_shared_prefix, value_shared_prefix, actual_shared_prefix_len, key,
-                              int(num_key_value_heads), int(block_size))
+                              int(num_key_value_heads), int(block_size), antiquant_mode)
         args = tens[:1] + lists + opt + [seq_arr] + quant + [
             int(num_heads), float(scale_value), str(input_layout).encode(), int(num_key_value_heads), int(block_size),
             int(inner_precise), tens[1]]
@@ -233,7 +237,7 @@ def sparse_paged_fusion_attention(query: torch.Tensor, key: torch.Tensor, value:
                                   softmax_lse: Optional[torch.Tensor] = None,
                                   key_shared_prefix: Optional[torch.Tensor] = None,
                                   value_shared_prefix: Optional[torch.Tensor] = None,
-                                  actual_shared_prefix_len: Optional[int] = None
+                                  actual_shared_prefix_len: Optional[int] = None, antiquant_mode: int = 0
                                   ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """CentSelect + sparse paged attention in one kernel launch (add_custom.py:96-135).  Returns
     (attention_out, block_position, max_page_position_length) — the 3-tuple of the registered schema
@@ -256,7 +260,7 @@ def sparse_paged_fusion_attention(query: torch.Tensor, key: torch.Tensor, value:
     try:
         _set_knobs(k, sink_recent, max_pages_cap)
         _set_attention_extras(softmax_lse, key_shared_prefix, value_shared_prefix, actual_shared_prefix_len, key,
-                              int(num_key_value_heads), int(block_size))
+                              int(num_key_value_heads), int(block_size), antiquant_mode)
         _abi.run(_abi.aclnnSparsePagedFusionAttentionGetWorkspaceSize, _abi.aclnnSparsePagedFusionAttention, args,
                  dev, "aclnnSparsePagedFusionAttention")
     finally:

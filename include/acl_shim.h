@@ -128,6 +128,14 @@ SPFA_API aclnnStatus spfaSetActualSeqLengthsDevice(const int64_t* deviceLengths,
  * token-level variant the reference sketches in tests/ifa_v5_case_tkp.py:53-54.  Head dims 64 and 128; pseShift /
  * attenMask are refused; every q head is streamed as its own pass. */
 SPFA_API aclnnStatus spfaSetTokenPositions(int enable);
+/* One-shot: antiquant mode of the next phase 1 of the two sparse attention ops on this thread — the antiquantMode
+ * attribute of the kernel the sparse ops were derived from (sparse_paged_fusion_attention_tiling.cc:719-765,982-984),
+ * which their aclnn signatures do not carry.  0 (default): antiquantScale / antiquantOffset are [2, Hkv, D] (per channel)
+ * or [2] (per tensor) in the query dtype.  1: per token — float32 [2, B, S] with S >= blocktable columns * blockSize
+ * (+ the shared prefix length), key parameters first: K_t = (k_t + offset[0, b, c]) * scale[0, b, c] and likewise V with
+ * index 1, c being the token's column in the gathered sequence (prefix tokens, then list slot * blockSize + token), as
+ * for pseShift / attenMask (sparse_paged_fusion_attention_split_Bbn2s2_Us2.h:2039-2043, 2262-2266, 3711-3822). */
+SPFA_API aclnnStatus spfaSetAntiquantMode(int64_t mode);
 /* One-shot: the next aclnnSparsePagedAttentionGetWorkspaceSize / aclnnSparsePagedFusionAttentionGetWorkspaceSize on
  * this thread also writes the softmax log-sum-exp of every output row, ln(sum_t exp(score_t)) as float32, to this
  * DEVICE array of n >= B * numHeads values laid out [B, numHeads] — the softmaxLse output of the reference kernel

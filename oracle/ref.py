@@ -193,7 +193,7 @@ def sparse_paged_attention(q, key_cache, value_cache, block_table, block_positio
                            exact: bool = True, pse_shift=None, atten_mask=None,
                            quant_scale2=None, quant_offset2=None, token_level: bool = False,
                            key_shared_prefix=None, value_shared_prefix=None, shared_prefix_len=None,
-                           return_lse: bool = False):
+                           return_lse: bool = False, antiquant_mode: int = 0):
     """Decode attention over a virtual sequence of selected pages.  Returns fp32 [B,Hq,D].
 
     Virtual token t of batch b / head row r lives in virtual page j = t // bs; its
@@ -225,6 +225,10 @@ def sparse_paged_attention(q, key_cache, value_cache, block_table, block_positio
     reference's tests/ifa_v5_case_tkp.py:53-54): entry j < actual_seq_lengths[b] before the first
     0x7fffffff is token t, row t % bs of page block_table[b, t // bs].
 
+    antiquant_mode=1 (per token, …Us2.h:2039-2043, 3711-3822): antiquant_scale / antiquant_offset are float32
+    [2, B, S] over the columns of the gathered sequence (as pse_shift / atten_mask): K_t = (k_t + off[0, b, c]) *
+    scale[0, b, c], V_t = (v_t + off[1, b, c]) * scale[1, b, c].  exact mode.
+
     key_shared_prefix / value_shared_prefix ([1, S, Hkv * D] | [1, S, Hkv, D] for a BSH cache, [1, Hkv, S, D] for
     BNSD; the KV dtype, int8 with the same antiquant parameters): every row attends the first shared_prefix_len
     (default S) prefix tokens in front of its gathered pages; pse_shift / atten_mask columns then start with the
@@ -248,7 +252,13 @@ def sparse_paged_attention(q, key_cache, value_cache, block_table, block_positio
     P = bp.shape[2]
     bt = np.asarray(block_table)
     quant = antiquant_scale is not None
-    if quant:
+    per_token = quant and antiquant_mode == 1
+    assert not per_token or exact
+    if per_token:
+        pt_s = np.asarray(antiquant_scale, dtype=np.float64).reshape(2, B, -1)
+        pt_o = None if antiquant_offset is None else np.asarray(antiquant_offset, dtype=np.float64).reshape(2, B, -1)
+        a_o = None
+    elif quant:
         def _params(t):
             t = np.asarray(t, dtype=np.float32)
             if t.size == 2:
@@ -284,7 +294,7 @@ def sparse_paged_attention(q, key_cache, value_cache, block_table, block_positio
             else:
                 n_tok = n_pages * block_size
             qv = q[b, h].astype(facc)
-            if quant:
+            if quant and not per_token:
                 qv = qv * a_s[0, n2].astype(facc)
             ks, vs, cols = [], [], []
             if n_pre:
@@ -324,8 +334,14 @@ def sparse_paged_attention(q, key_cache, value_cache, block_table, block_positio
             if exact:
                 K = np.concatenate(ks).astype(np.float64)
                 V = np.concatenate(vs).astype(np.float64)
-                s = (K @ qv) * np.float64(scale)
                 col = np.concatenate(cols)
+                if per_token:
+                    if pt_o is not None:
+                        K = K + pt_o[0, b, col][:, None]
+                        V = V + pt_o[1, b, col][:, None]
+                    K = K * pt_s[0, b, col][:, None]
+                    V = V * pt_s[1, b, col][:, None]
+                s = (K @ qv) * np.float64(scale)
                 if pse is not None:
                     s = s + pse[b if pse.shape[0] > 1 else 0, h, 0, col].astype(np.float64)
                 if amask is not None:
@@ -353,7 +369,7 @@ def sparse_paged_attention(q, key_cache, value_cache, block_table, block_positio
                     o = o * alpha + (p_ @ Vp.astype(np.float32)).astype(np.float32)
                     m = m_new
                 o = o / l
-            if quant:
+            if quant and not per_token:
                 if a_o is not None:
                     o = o + a_o[1, n2].astype(facc)
                 o = o * a_s[1, n2].astype(facc)
@@ -401,7 +417,7 @@ def sparse_paged_fusion_attention(q, key_cache, value_cache, block_table, l1_cen
                                   antiquant_offset=None, p_round=None, exact: bool = True,
                                   pse_shift=None, atten_mask=None, quant_scale2=None, quant_offset2=None,
                                   key_shared_prefix=None, value_shared_prefix=None, shared_prefix_len=None,
-                                  return_lse: bool = False):
+                                  return_lse: bool = False, antiquant_mode: int = 0):
     """cent_select then attention over each q head's own page list
     (sparse_paged_fusion_attention.cpp:56-76; attention runs with
     actualSeqLengths := max_page_position_length and blockPosition := the rows just
@@ -426,7 +442,7 @@ def sparse_paged_fusion_attention(q, key_cache, value_cache, block_table, l1_cen
                                  pse_shift=pse_shift, atten_mask=atten_mask, quant_scale2=quant_scale2,
                                  quant_offset2=quant_offset2, key_shared_prefix=key_shared_prefix,
                                  value_shared_prefix=value_shared_prefix, shared_prefix_len=shared_prefix_len,
-                                 return_lse=return_lse)
+                                 return_lse=return_lse, antiquant_mode=antiquant_mode)
     return out, pos, len8, max8
 
 

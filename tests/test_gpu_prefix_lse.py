@@ -282,3 +282,109 @@ def test_extras_errors(H):
     # a failed call leaves nothing armed: the next plain call neither reads a prefix nor writes an LSE
     out = H.call_attention(*args)
     assert torch.isfinite(out.float()).all()
+
+
+def _per_token_params(rng, B, S, with_offset):
+    sc = (rng.random((2, B, S)) * 0.02 + 0.002).astype(np.float32)
+    of = (rng.standard_normal((2, B, S)) * 4.0).astype(np.float32) if with_offset else None
+    return sc, of
+
+
+@pytest.mark.parametrize("Hq,Hkv,rows,D,bs,layout,with_offset,n_pre", [
+    (8, 8, "kv", 128, 128, "BSH", True, 0),
+    (8, 2, "kv", 128, 128, "BSH", True, 0),          # a group: every head becomes a pass of its own
+    (8, 2, "q", 128, 32, "BNSD", False, 0),
+    (4, 4, "kv", 64, 64, "BSH", True, 0),
+    (8, 2, "kv", 128, 128, "BSH", True, 200),        # the prefix tokens come first in the parameter columns
+])
+@pytest.mark.parametrize("max_split", [16, 1])
+def test_per_token_antiquant_vs_oracle(H, Hq, Hkv, rows, D, bs, layout, with_offset, n_pre, max_split):
+    """Per-token parameters (float32 [2, B, S] over the gathered columns).  Parity unpinned; the per-channel form of the
+    same numbers is an independent check below."""
+    from custom_ops import _abi
+    rng, q, k, v, table, pos, act = _case(900 + Hq + D, "i8", Hq, Hkv, rows, D, bs, layout=layout)
+    B = q.shape[0]
+    S = table.shape[1] * bs + n_pre + 5
+    sc, of = _per_token_params(rng, B, S, with_offset)
+    pre_kw, pre_okw = {}, {}
+    if n_pre:
+        kp, vp = _prefix(rng, "i8", n_pre, Hkv, D, layout)
+        pre_kw = dict(key_shared_prefix=H.dev(kp), value_shared_prefix=H.dev(vp))
+        pre_okw = dict(key_shared_prefix=kp, value_shared_prefix=vp)
+    scale = D ** -0.5
+    want, wlse = ref.sparse_paged_attention(q, k, v, table, pos, act, Hq, Hkv, scale, bs, layout, antiquant_scale=sc,
+                                            antiquant_offset=of, antiquant_mode=1, return_lse=True, **pre_okw)
+    lse = torch.empty((B, Hq), dtype=torch.float32, device=H.DEV)
+    _abi.check(_abi.spfaSetMaxSplit(max_split), "spfaSetMaxSplit")
+    try:
+        out = H.call_attention(H.dev(q), H.dev(k), H.dev(v), H.dev(table), H.dev(pos), torch.tensor(act), Hq, Hkv, scale,
+                               bs, out_dtype=torch.float32, antiq_scale=H.dev(sc),
+                               antiq_offset=None if of is None else H.dev(of), antiquant_mode=1, softmax_lse=lse, **pre_kw)
+    finally:
+        _abi.spfaSetMaxSplit(16)
+    err = float(parity.rel_err(H.f32(out), want).max())
+    assert err <= TOL, f"max rel err {err:.3e}"
+    _lse_close(lse.cpu().numpy(), wlse)
+
+
+def test_per_token_equals_per_tensor_when_constant(H):
+    """Independent of the oracle: per-token parameters that are the same for every token are per-tensor parameters."""
+    Hq, Hkv, D, bs = 8, 2, 128, 128
+    rng, q, k, v, table, pos, act = _case(47, "i8", Hq, Hkv, "kv", D, bs)
+    B, S = q.shape[0], table.shape[1] * bs
+    a_s = np.array([0.0125, 0.03125], np.float16)          # exact in f16 and f32
+    a_o = np.array([3.0, -1.5], np.float16)
+    sc = np.broadcast_to(a_s.astype(np.float32).reshape(2, 1, 1), (2, B, S)).copy()
+    of = np.broadcast_to(a_o.astype(np.float32).reshape(2, 1, 1), (2, B, S)).copy()
+    args = (H.dev(q), H.dev(k), H.dev(v), H.dev(table), H.dev(pos), torch.tensor(act), Hq, Hkv, D ** -0.5, bs)
+    tensor = H.call_attention(*args, out_dtype=torch.float32, antiq_scale=H.dev(a_s), antiq_offset=H.dev(a_o))
+    token = H.call_attention(*args, out_dtype=torch.float32, antiq_scale=H.dev(sc), antiq_offset=H.dev(of),
+                             antiquant_mode=1)
+    # two different kernels (the group pass on the matrix cores against one pass per head): fp32 rounding apart
+    assert float(parity.rel_err(H.f32(token), H.f32(tensor)).max()) <= 2e-4
+
+
+def test_fusion_with_per_token_antiquant(H):
+    Hq, Hkv, D, C, topk, bs = 8, 2, 128, 256, 8, 128
+    seq_lens = [4000, 32 * 128, 129, 77]
+    B, kv_page_len, max_page = len(seq_lens), 96, 80
+    q, l1 = datagen.cent_case(91, B, Hq, Hkv, D, C, grid=True)
+    ids, table, seq = datagen.page_case(91, Hkv, C, kv_page_len, B + 1, max_page, seq_lens)
+    k, v = datagen.kv_case(91, kv_page_len, bs, Hkv, D, "BSH", dist="randn", dtype="i8")
+    rng = datagen.rng_for(9)
+    sc, of = _per_token_params(rng, B, max_page * bs, True)
+    scale = D ** -0.5
+    want, wpos, wlen, wmax = ref.sparse_paged_fusion_attention(q, k, v, table, l1, ids, seq, Hq, Hkv, scale, bs, topk, 256,
+                                                               antiquant_scale=sc, antiquant_offset=of, antiquant_mode=1)
+    out, pos, plen, pmax = H.call_fusion(H.dev(q), H.dev(k), H.dev(v), H.dev(table), H.dev(l1), H.dev(ids), H.dev(seq),
+                                         Hq, Hkv, scale, bs, topk, out_dtype=torch.float32, antiq_scale=H.dev(sc),
+                                         antiq_offset=H.dev(of), antiquant_mode=1)
+    assert np.array_equal(pos.cpu().numpy(), wpos) and np.array_equal(plen.cpu().numpy(), wlen)
+    assert np.array_equal(pmax.cpu().numpy(), wmax)
+    err = float(parity.rel_err(H.f32(out), want).max())
+    assert err <= TOL, f"max rel err {err:.3e}"
+
+
+def test_per_token_antiquant_errors(H):
+    from custom_ops._abi import AclError
+    B, Hq, D, bs = 2, 4, 128, 128
+    q = H.dev(np.zeros((B, Hq, D), np.float16))
+    kv8 = H.dev(np.zeros((4, bs, Hq * D), np.int8))
+    kv16 = H.dev(np.zeros((4, bs, Hq * D), np.float16))
+    table = H.dev(np.zeros((B, 4), np.int32))
+    pos = H.dev(np.zeros((B, Hq, 4), np.int32))
+    good = H.dev(np.ones((2, B, 4 * bs), np.float32))
+    with pytest.raises(AclError, match="needs an int8 KV cache"):
+        H.call_attention(q, kv16, kv16, table, pos, [128], Hq, Hq, 1.0, bs, antiquant_mode=1)
+    with pytest.raises(AclError, match="float32 \\[2, B, S\\]"):
+        H.call_attention(q, kv8, kv8, table, pos, [128], Hq, Hq, 1.0, bs, antiquant_mode=1,
+                         antiq_scale=H.dev(np.ones((2, Hq, D), np.float16)))
+    with pytest.raises(AclError, match="less than sMax"):
+        H.call_attention(q, kv8, kv8, table, pos, [128], Hq, Hq, 1.0, bs, antiquant_mode=1,
+                         antiq_scale=H.dev(np.ones((2, B, 4 * bs - 1), np.float32)))
+    with pytest.raises(AclError, match="antiquant mode"):
+        H.call_attention(q, kv8, kv8, table, pos, [128], Hq, Hq, 1.0, bs, antiquant_mode=2, antiq_scale=good)
+    # the mode was one-shot: a per-channel call right after works with per-channel shapes
+    out = H.call_attention(q, kv8, kv8, table, pos, [128], Hq, Hq, 1.0, bs,
+                           antiq_scale=H.dev(np.ones((2, Hq, D), np.float16)))
+    assert torch.isfinite(out.float()).all()
