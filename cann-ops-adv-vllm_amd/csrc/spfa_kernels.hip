@@ -27,10 +27,13 @@
 //                  folded into the accumulators, out = (P.V / l + offset_v) * scale_v
 //                  (sparse_paged_fusion_attention_split_Bbn2s2_Us2.h:2647,2651,4160-4174).
 //
-// Files: this one holds the small device helpers and the host-side launchers; the device code proper is included
-// from spfa_select.inc (scoring, top-k, page selection), spfa_cent_kernels.inc (standalone scoring ops),
-// spfa_pipeline.inc (work items, queues, sharing of last items), spfa_stream_valu.inc / spfa_stream_mfma.inc (the
-// two K/V streamers) and spfa_attn_kernel.inc (the persistent attention kernel).
+// Files: this translation unit holds the standalone ops (scoring, position selection, cluster assignment), the small
+// service kernels and the host-side launchers; the attention kernels compile as one translation unit per KV element
+// type (spfa_attn_f16.hip, spfa_attn_bf16.hip, spfa_attn_i8.hip, all through spfa_attn_tu.inc).  The device code
+// proper lives in spfa_common.inc (helpers), spfa_select.inc (scoring, top-k, page selection), spfa_cent_kernels.inc
+// (standalone scoring ops), spfa_assign.inc, spfa_pipeline.inc (work items, queues, sharing of last items),
+// spfa_stream_valu.inc / spfa_stream_mfma.inc (the two K/V streamers) and spfa_attn_kernel.inc (the persistent
+// attention kernel).
 #include "spfa_params.h"
 
 #include <hip/hip_runtime.h>
@@ -41,168 +44,11 @@
 namespace spfa {
 namespace {
 
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
-// readfirstlane makes the wave index provably uniform for the compiler: everything derived from it
-// (page cursors, buffer descriptors, loop bounds) then lives in SGPRs and buffer loads need no waterfall loop.
-__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
-__device__ __forceinline__ unsigned long long lanes_below(int lane) { return (1ull << lane) - 1ull; }
-
-// LDS traffic of ONE wave is in order; this only stops the compiler from caching or moving it.
-__device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
-// Data that one workgroup hands to another inside a launch is written and read with agent-scope accesses, which go
-// past the non-coherent cache levels, and the writer waits for its stores before it signals with an atomic.  No
-// release/acquire fence is used: on this part a fence writes back / invalidates a whole L2, and hundreds of them per
-// XCD while the other workgroups still stream K/V cost more than the sharing saves.
-template <typename T>
-__device__ __forceinline__ void st_agent(T* ptr, T v) { __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-template <typename T>
-__device__ __forceinline__ T ld_agent(const T* ptr) {
-    return __hip_atomic_load(const_cast<T*>(ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void wait_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
-// fp32 -> uint32 whose unsigned order equals the float order (-0 == +0, +NaN largest).
-__device__ __forceinline__ uint32_t score_key(float x) {
-    x = x + 0.0f;
-    uint32_t u = __float_as_uint(x);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-
-template <int CTRL>
-__device__ __forceinline__ float dpp(float x) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
-}
-// Sum over the LPT consecutive lanes that share one token; every lane of the group gets the sum.
-template <int LPT>
-__device__ __forceinline__ float group_allsum(float x) {
-    if constexpr (LPT >= 64) x += __shfl_xor(x, 32);
-    if constexpr (LPT >= 32) x += __shfl_xor(x, 16);
-    if constexpr (LPT >= 16) { x += dpp<0x128>(x); x += dpp<0x124>(x); }   // row_ror 8, 4
-    else if constexpr (LPT == 8) x += dpp<0x141>(x);                       // row_half_mirror
-    x += dpp<0x4E>(x);                                                     // quad_perm [2,3,0,1]
-    x += dpp<0xB1>(x);                                                     // quad_perm [1,0,3,2]
-    return x;
-}
-
-__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32
-__device__ __forceinline__ float bf16_lo(uint32_t w) { return __uint_as_float(w << 16); }
-__device__ __forceinline__ float bf16_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
-__device__ __forceinline__ float f16_bits(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
-__device__ __forceinline__ float load_qk_elem(const void* p, int dtype, long long i) {
-    uint16_t h = ((const uint16_t*)p)[i];
-    return dtype == kBF16 ? __uint_as_float((uint32_t)h << 16) : f16_bits(h);
-}
-
+#include "spfa_common.inc"
 #include "spfa_select.inc"
 #include "spfa_cent_kernels.inc"
-#include "spfa_pipeline.inc"
-#include "spfa_stream_valu.inc"
-#include "spfa_stream_mfma.inc"
-#include "spfa_attn_kernel.inc"
+#include "spfa_pipeline.inc"   // build knobs and wave counts of the attention kernels (sizes the host reports)
 #include "spfa_assign.inc"
-
-constexpr int kMaxDevices = 64;
-// Raise a kernel's dynamic-LDS limit on the current device when `bytes` exceeds what was set before (the limit is a
-// property of the kernel on a device, and executors planned with different sizes may be launched in any order).
-// `table` holds the limit already set per device.
-hipError_t ensure_lds_limit(const void* kern, int* table, size_t bytes) {
-    if (bytes <= 48 * 1024) return hipSuccess;
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    if (dev < 0 || dev >= kMaxDevices) return hipErrorInvalidDevice;
-    if (__atomic_load_n(&table[dev], __ATOMIC_ACQUIRE) >= (int)bytes) return hipSuccess;
-    e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e != hipSuccess) return e;
-    int seen = __atomic_load_n(&table[dev], __ATOMIC_RELAXED);
-    while (seen < (int)bytes && !__atomic_compare_exchange_n(&table[dev], &seen, (int)bytes, false, __ATOMIC_RELEASE,
-                                                              __ATOMIC_RELAXED)) {}
-    return hipSuccess;
-}
-
-// cap_out != nullptr (phase 1): set the LDS limit, ask the runtime how many workgroups fit a CU, report the resident
-// grid.  Otherwise (phase 2): launch; with p.grid_cap from phase 1 this is nothing but the launch itself.
-template <typename KVT, int NQ, int LPT, bool MFMA, int VAR = 0>
-hipError_t launch_attn_one(const AttnParams& p, hipStream_t s, long long* cap_out) {
-    auto kern = attn_kernel<KVT, NQ, LPT, MFMA, VAR>;
-    static int lds_limit[kMaxDevices];
-    long long cap = p.grid_cap;
-    if (cap_out || cap <= 0) {
-        hipError_t e = ensure_lds_limit((const void*)kern, lds_limit, p.lds_bytes);
-        if (e != hipSuccess) return e;
-        int occ = 0;
-        const int n_cu = device_cu_count();
-        if (n_cu <= 0) return hipErrorNoDevice;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, attn_threads(MFMA, sizeof(KVT) == 1), p.lds_bytes);
-        if (e != hipSuccess) return e;
-        int blocks_per_cu = occ < 1 ? 1 : occ;   // residency of the persistent grid
-        // 8 streamer waves per CU already saturate HBM; a third workgroup only deepens the memory queues
-        if (blocks_per_cu > SPFA_WGS_PER_CU) blocks_per_cu = SPFA_WGS_PER_CU;
-        cap = (long long)n_cu * blocks_per_cu;
-        static bool said = false;
-        if (!said && getenv("SPFA_DEBUG")) {
-            said = true;
-            fprintf(stderr, "[spfa] attn blocks/CU=%d CUs=%d lds=%zu mfma=%d\n", blocks_per_cu, n_cu, p.lds_bytes, (int)MFMA);
-        }
-    }
-    if (cap_out) { *cap_out = cap; return hipSuccess; }   // planning: how many workgroups can be resident
-    const bool per_head = (p.mode == 0 && p.pos_rows == p.Hq && p.G > 1);
-    const int g_eff = per_head ? 1 : p.G;
-    const int nq = MFMA ? p.rows_per_pass : NQ;
-    const long long total = (long long)p.B * (per_head ? p.Hq : p.Hkv) * ((g_eff + nq - 1) / nq) * p.n_split;
-    if (total == 0) return hipSuccess;
-    if (p.n_split > 1 && total > cap) return hipErrorInvalidConfiguration;   // a split needs one workgroup per unit
-    const dim3 grid((unsigned)(total < cap ? total : cap));
-    // pre-scored items: the kernel takes the grid as the distance between a workgroup's items
-    if (p.pre_items > 1 && (total != (long long)p.pre_items * grid.x || grid.x % (unsigned)p.Hkv != 0 || p.mode != 1 || g_eff > nq ||
-                            p.pre_items * nq > 16))
-        return hipErrorInvalidConfiguration;
-    hipLaunchKernelGGL(kern, grid, dim3(attn_threads(MFMA, sizeof(KVT) == 1)), p.lds_bytes, s, p);
-    return hipGetLastError();
-}
-
-// One q head per pass (MHA, or a group whose heads bring their own lists), or int8 KV: VALU streamer.
-template <typename KVT, int NQ>
-hipError_t launch_attn_valu(const AttnParams& p, int lpt, hipStream_t s, long long* cap_out) {
-    switch (lpt) {
-#ifndef SPFA_EXPLORE
-        case 4: return launch_attn_one<KVT, NQ, 4, false>(p, s, cap_out);
-        case 8: return launch_attn_one<KVT, NQ, 8, false>(p, s, cap_out);
-        case 32: return launch_attn_one<KVT, NQ, 32, false>(p, s, cap_out);
-        case 64:   // 1024-byte head rows: f16 / bf16 at D = 512 (int8 rows end at 512 bytes)
-            if constexpr (sizeof(KVT) == 2 && NQ == 1) return launch_attn_one<KVT, NQ, 64, false>(p, s, cap_out);
-            break;
-#endif
-        case 16: return launch_attn_one<KVT, NQ, 16, false>(p, s, cap_out);
-    }
-    return hipErrorInvalidValue;
-}
-
-// Several q heads share the K/V rows (f16 / bf16): MFMA streamer.
-template <typename KVT>
-hipError_t launch_attn_mfma(const AttnParams& p, int lpt, hipStream_t s, long long* cap_out) {
-    switch (lpt) {
-#ifndef SPFA_EXPLORE
-        case 4: return launch_attn_one<KVT, 16, 4, true>(p, s, cap_out);
-        case 8: return launch_attn_one<KVT, 16, 8, true>(p, s, cap_out);
-        case 32:
-            if constexpr (sizeof(KVT) == 2) return launch_attn_one<KVT, 16, 32, true>(p, s, cap_out);
-            break;
-#endif
-        case 16: return launch_attn_one<KVT, 16, 16, true>(p, s, cap_out);
-    }
-    return hipErrorInvalidValue;
-}
 
 }  // namespace
 
@@ -292,69 +138,16 @@ int attention_rows_per_pass(int G, int kv_dtype, int D) {
     return G < 16 ? G : 16;                     // MFMA streamer: up to 16 columns
 }
 
+// One translation unit per KV element type holds the attention kernels (spfa_attn_f16.hip, spfa_attn_bf16.hip,
+// spfa_attn_i8.hip).
+hipError_t launch_attention_f16(const AttnParams& p, hipStream_t s, long long* cap_out);
+hipError_t launch_attention_bf16(const AttnParams& p, hipStream_t s, long long* cap_out);
+hipError_t launch_attention_i8(const AttnParams& p, hipStream_t s, long long* cap_out);
 hipError_t launch_attention(const AttnParams& p, hipStream_t s, long long* cap_out) {
-    const int nq = p.rows_per_pass;
-    const int esize = (p.kv_dtype == kI8) ? 1 : 2;
-    const int lpt = p.D * esize / 16;
-#ifndef SPFA_EXPLORE
-    if (p.token_mode) {   // token-level lists: one q head per pass, head dims 64 and 128
-        if (nq != 1 || p.mode != 0) return hipErrorInvalidValue;
-        switch (p.kv_dtype) {
-            case kF16:
-                if (lpt == 16) return launch_attn_one<_Float16, 1, 16, false, 1>(p, s, cap_out);
-                if (lpt == 8) return launch_attn_one<_Float16, 1, 8, false, 1>(p, s, cap_out);
-                break;
-            case kBF16:
-                if (lpt == 16) return launch_attn_one<__bf16, 1, 16, false, 1>(p, s, cap_out);
-                if (lpt == 8) return launch_attn_one<__bf16, 1, 8, false, 1>(p, s, cap_out);
-                break;
-            case kI8:
-                if (lpt == 8) return launch_attn_one<int8_t, 1, 8, false, 1>(p, s, cap_out);
-                if (lpt == 4) return launch_attn_one<int8_t, 1, 4, false, 1>(p, s, cap_out);
-                break;
-        }
-        return hipErrorInvalidValue;
-    }
-    if (p.antiq_per_token) {   // int8 KV with per-token parameters: one q head per pass
-        if (nq != 1 || p.kv_dtype != kI8) return hipErrorInvalidValue;
-        switch (lpt) {
-            case 4: return launch_attn_one<int8_t, 1, 4, false, 2>(p, s, cap_out);
-            case 8: return launch_attn_one<int8_t, 1, 8, false, 2>(p, s, cap_out);
-            case 16: return launch_attn_one<int8_t, 1, 16, false, 2>(p, s, cap_out);
-            case 32: return launch_attn_one<int8_t, 1, 32, false, 2>(p, s, cap_out);
-        }
-        return hipErrorInvalidValue;
-    }
-#endif
-    if (attention_uses_mfma(nq, p.kv_dtype, p.D)) {
-        if (nq > 16) return hipErrorInvalidValue;
-#ifdef SPFA_EXPLORE
-        if (p.kv_dtype == kF16) return launch_attn_mfma<_Float16>(p, lpt, s, cap_out);
-#ifdef SPFA_EXPLORE_I8
-        if (p.kv_dtype == kI8 && lpt == 8) return launch_attn_one<int8_t, 16, 8, true>(p, s, cap_out);
-#endif
-        return hipErrorInvalidValue;
-#else
-        switch (p.kv_dtype) {
-            case kF16: return launch_attn_mfma<_Float16>(p, lpt, s, cap_out);
-            case kBF16: return launch_attn_mfma<__bf16>(p, lpt, s, cap_out);
-            case kI8: return launch_attn_mfma<int8_t>(p, lpt, s, cap_out);
-        }
-        return hipErrorInvalidValue;
-#endif
-    }
     switch (p.kv_dtype) {
-        case kF16: if (nq == 1) return launch_attn_valu<_Float16, 1>(p, lpt, s, cap_out); break;
-#ifdef SPFA_EXPLORE_I8
-        case kI8: if (nq == 1 && lpt == 8) return launch_attn_one<int8_t, 1, 8, false>(p, s, cap_out); break;
-#endif
-#ifndef SPFA_EXPLORE
-        case kBF16: if (nq == 1) return launch_attn_valu<__bf16, 1>(p, lpt, s, cap_out); break;
-        case kI8:
-            if (nq == 1) return launch_attn_valu<int8_t, 1>(p, lpt, s, cap_out);
-            if (nq == 4 && lpt == 32) return launch_attn_one<int8_t, 4, 32, false>(p, s, cap_out);
-            break;
-#endif
+        case kF16: return launch_attention_f16(p, s, cap_out);
+        case kBF16: return launch_attention_bf16(p, s, cap_out);
+        case kI8: return launch_attention_i8(p, s, cap_out);
     }
     return hipErrorInvalidValue;
 }

@@ -7,6 +7,6 @@ while [ $# -ge 2 ]; do
   name=$1; flags=$2; shift 2
   out=../lib_var/$name
   mkdir -p $out
-  make -s OUT_DIR=$out EXTRA="-DSPFA_EXPLORE $flags" 2>&1 | grep -E "error" -A4 || true
+  make -s -j6 OUT_DIR=$out EXTRA="-DSPFA_EXPLORE $flags" 2>&1 | grep -E "error" -A4 || true
   echo "built $name: $flags"
 done
