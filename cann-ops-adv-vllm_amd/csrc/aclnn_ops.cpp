@@ -776,7 +776,7 @@ static size_t carve_lds(spfa::AttnParams& p, size_t nq) {
     p.off_keys = (int)off;
     if (p.mode == 1) off += align16(sel_rows * p.Cp * 4);                  // score keys (selector wave)
     p.off_cbits = (int)off;
-    const size_t max_waves = 8;   // upper bound of the waves of a workgroup (streamers + selectors)
+    const size_t max_waves = 16;   // upper bound of the waves of a workgroup (streamers + selectors)
     if (p.mode == 1)   // top-k cluster bitmaps (one per wave that selects a row of the first item) + 16 row lengths
         off += align16((sel_rows < max_waves ? sel_rows : max_waves) * (size_t)(p.Cp / 32) * 4) + 64;
     p.off_pbits = (int)off;
@@ -795,6 +795,7 @@ static size_t carve_lds(spfa::AttnParams& p, size_t nq) {
     if (mfma) off += sw * 32 * (p.D * 2 + 32);                             // V tile images of the streamer waves
     p.off_stage = (int)off;
     if (p.mode == 1) off += (size_t)spfa::attention_stage_bytes(mfma, p.kv_dtype, p.D);   // centroid tiles of the scoring waves
+    p.score_waves = spfa::attention_score_waves(mfma, p.kv_dtype, p.D);
     return off;
 }
 
@@ -858,10 +859,18 @@ static void plan_workspace(aclOpExecutor* e) {
     // kernel would take as well (J * R <= 16 rows), lose: GQA 32/8 S=32k 0.241 -> 0.242 ms, S=128k k=64 0.752 -> 0.767 ms —
     // their first selection walks J * R rows with 6 or 8 waves, all of it exposed.
     p.pre_items = 0;
+    p.pre_lists = 0;
+    const bool one_head = p.rows_per_pass == 1 && p.G == 1;
+    // Group passes (one pass per group on the matrix-core streamer): only the SCORES of the workgroup's items are taken
+    // in the shared pass; their top-k and page selection stay with the selector waves, beside the page stream.  What
+    // leaves the hidden part is the centroid pass itself, whose LDS and L2 traffic slows the streamers of the same CU.
+    const bool one_group = p.G > 1 && p.G <= p.rows_per_pass && spfa::attention_uses_mfma(p.rows_per_pass, p.kv_dtype, p.D) &&
+                           !p.pse && !p.amask;
     if (g_shared_scoring && p.mode == 1 && p.n_split == 1 && cap > 0 && items > cap && items % cap == 0 &&
-        p.rows_per_pass == 1 && p.G == 1 && cap % p.Hkv == 0 && items / cap <= 8) {
+        (one_head || one_group) && cap % p.Hkv == 0 && (items / cap) * p.rows_per_pass <= (one_head ? 8 : 16)) {
         spfa::AttnParams trial = p;
         trial.pre_items = (int)(items / cap);
+        trial.pre_lists = one_head ? 1 : 0;
         trial.lds_bytes = carve_lds(trial, (size_t)p.rows_per_pass);
         long long cap2 = 0;
         if (trial.lds_bytes <= kMaxLds && spfa::launch_attention(trial, nullptr, &cap2) == hipSuccess && cap2 == cap) {

@@ -159,6 +159,9 @@ struct AttnParams {
     // > 1: every workgroup owns exactly pre_items items (its own index, then one grid further each time), all of one kv
     // head: their rows are scored in ONE pass over the head's centroids before the first item is streamed
     int pre_items;
+    // with pre_items > 1 — 1: the page lists of all those items are built before the first is streamed as well (one wave
+    // per row); 0: only the scores are taken ahead, top-k and page selection of items 2.. stay with the selector waves
+    int pre_lists;
     // page-list split for small batches: n_split workgroups per item (1: off)
     int n_split;
     // sharing of every workgroup's last item (n_split == 1 only): boards and their data areas in the workspace
@@ -174,6 +177,9 @@ struct AttnParams {
     unsigned* split_done;          // [items] arrival counters (workspace), zeroed before every launch
     float* split_partials;         // [items * n_split][rows_per_pass][D + 2] un-normalised states (workspace)
     unsigned long long* debug;     // diagnostic builds only: [grid][16 items][16 stamps], else null
+    // waves of a workgroup that share the centroid pass of the first item (each needs an LDS tile of its own; the
+    // other waves wait): all of them for head dims up to 128, fewer for longer rows (VALU form)
+    int score_waves;
     // LDS carve (bytes from the dynamic base)
     int off_keys, off_cbits, off_pbits, off_list, off_comb, off_qst, off_hdr, off_vst, off_stage;
     size_t lds_bytes;
@@ -207,6 +213,7 @@ int attention_stream_waves(bool mfma, int kv_dtype);
 // LDS tiles through which the centroid pass turns memory order into matrix-core operand order: bytes at off_stage of
 // the attention kernels, and at the end of the dynamic LDS of the cent kernels.
 int attention_stage_bytes(bool mfma, int kv_dtype, int D);
+int attention_score_waves(bool mfma, int kv_dtype, int D);   // AttnParams::score_waves of a plan
 int cent_stage_bytes(int D);      // kCentWaves tiles
 int assign_stage_bytes(int D);    // 4 tiles
 
