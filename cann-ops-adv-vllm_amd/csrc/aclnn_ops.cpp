@@ -62,6 +62,7 @@ thread_local int g_page_cap = 0;
 thread_local int g_max_split = 16;
 thread_local int g_tail_sharing = 1;
 thread_local int g_shared_scoring = 1;
+thread_local int g_geometry = 0;           // 0: planner's choice, 1: wide, 2: narrow workgroups of the one-q-head kernels
 thread_local int64_t g_page_size = 128;   // PAGESIZE of cent_select.cpp:17 / select_position.cpp:112
 thread_local const long long* g_act_seq_dev = nullptr;   // one-shot, consumed by the next attention plan
 thread_local int64_t g_act_seq_dev_n = 0;
@@ -317,6 +318,11 @@ aclnnStatus spfaSetMaxSplit(int64_t max_split) {
 }
 aclnnStatus spfaSetTailSharing(int enable) { g_tail_sharing = enable < 0 ? 0 : (enable > 2 ? 2 : enable); return ACLNN_SUCCESS; }
 aclnnStatus spfaSetSharedScoring(int enable) { g_shared_scoring = enable ? 1 : 0; return ACLNN_SUCCESS; }
+aclnnStatus spfaSetWorkgroupGeometry(int geometry) {
+    if (geometry < 0 || geometry > 2) return fail(ACLNN_ERR_PARAM_INVALID, "workgroup geometry %d: 0 (auto), 1 (wide) or 2 (narrow)", geometry);
+    g_geometry = geometry;
+    return ACLNN_SUCCESS;
+}
 aclnnStatus spfaSetPageSize(int64_t page_size) {
     if (page_size < 1 || page_size > 512) return fail(ACLNN_ERR_PARAM_INVALID, "page size %lld out of [1, 512]", (long long)page_size);
     g_page_size = page_size;
@@ -785,7 +791,7 @@ static size_t carve_lds(spfa::AttnParams& p, size_t nq) {
     off += align16((size_t)2 * p.max_entries * 8);                         // double-buffered page lists
     p.off_comb = (int)off;
     const bool mfma = spfa::attention_uses_mfma((int)nq, p.kv_dtype, p.D);
-    const size_t sw = (size_t)spfa::attention_stream_waves(mfma, p.kv_dtype);
+    const size_t sw = (size_t)spfa::attention_stream_waves(mfma, p.kv_dtype, p.narrow != 0);
     off += align16((size_t)2 * sw * nq * (p.D + 2) * 4);                   // streamer states of two items
     p.off_qst = (int)off;
     if (!mfma) off += align16((size_t)2 * nq * p.D * 4);                   // pre-scaled q rows (VALU streamer)
@@ -794,8 +800,8 @@ static size_t carve_lds(spfa::AttnParams& p, size_t nq) {
     p.off_vst = (int)off;
     if (mfma) off += sw * 32 * (p.D * 2 + 32);                             // V tile images of the streamer waves
     p.off_stage = (int)off;
-    if (p.mode == 1) off += (size_t)spfa::attention_stage_bytes(mfma, p.kv_dtype, p.D);   // centroid tiles of the scoring waves
-    p.score_waves = spfa::attention_score_waves(mfma, p.kv_dtype, p.D);
+    if (p.mode == 1) off += (size_t)spfa::attention_stage_bytes(mfma, p.kv_dtype, p.D, p.narrow != 0);   // centroid tiles of the scoring waves
+    p.score_waves = spfa::attention_score_waves(mfma, p.kv_dtype, p.D, p.narrow != 0);
     return off;
 }
 
@@ -866,8 +872,10 @@ static void plan_workspace(aclOpExecutor* e) {
     // leaves the hidden part is the centroid pass itself, whose LDS and L2 traffic slows the streamers of the same CU.
     const bool one_group = p.G > 1 && p.G <= p.rows_per_pass && spfa::attention_uses_mfma(p.rows_per_pass, p.kv_dtype, p.D) &&
                            !p.pse && !p.amask;
-    if (g_shared_scoring && p.mode == 1 && p.n_split == 1 && cap > 0 && items > cap && items % cap == 0 &&
-        (one_head || one_group) && cap % p.Hkv == 0 && (items / cap) * p.rows_per_pass <= (one_head ? 8 : 16)) {
+    auto try_scored_ahead = [&]() {
+        if (!(g_shared_scoring && p.mode == 1 && p.n_split == 1 && cap > 0 && items > cap && items % cap == 0 &&
+              (one_head || one_group) && cap % p.Hkv == 0 && (items / cap) * p.rows_per_pass <= (one_head ? 8 : 16)))
+            return false;
         spfa::AttnParams trial = p;
         trial.pre_items = (int)(items / cap);
         trial.pre_lists = one_head ? 1 : 0;
@@ -876,6 +884,41 @@ static void plan_workspace(aclOpExecutor* e) {
         if (trial.lds_bytes <= kMaxLds && spfa::launch_attention(trial, nullptr, &cap2) == hipSuccess && cap2 == cap) {
             trial.grid_cap = cap;
             p = trial;
+            return true;
+        }
+        return false;
+    };
+    const bool ahead = try_scored_ahead();
+    // The plain one-q-head kernel exists in two geometries: one workgroup of eight streamer waves per CU (wide: one pass
+    // over the centroids per CU at the start, eight items scored ahead) and two workgroups of four (narrow: twice the
+    // selector waves).  Wide wins whenever the selector has little to do beside the stream — lists given, every
+    // workgroup's items scored ahead, or at most one item per workgroup; a fused launch that pulls more items than that
+    // through the queue goes narrow, because one selector wave cannot prepare short lists as fast as eight streamers
+    // consume them.
+    const bool both = p.rows_per_pass == 1 && !p.token_mode && !p.antiq_per_token &&
+                      !spfa::attention_uses_mfma(p.rows_per_pass, p.kv_dtype, p.D);
+    const bool want_narrow = g_geometry == 2 || (g_geometry == 0 && p.mode == 1 && cap > 0 && items > cap && !ahead);
+    if (both && want_narrow && n_cu > 0) {
+        spfa::AttnParams trial = p;
+        trial.narrow = 1;
+        trial.pre_items = 0;
+        trial.pre_lists = 0;
+        trial.lds_bytes = carve_lds(trial, (size_t)p.rows_per_pass);
+        long long cap2 = 0;
+        trial.grid_cap = 0;
+        if (trial.lds_bytes <= kMaxLds && spfa::launch_attention(trial, nullptr, &cap2) == hipSuccess && cap2 > 0) {
+            trial.grid_cap = cap2;
+            p = trial;
+            cap = cap2;
+            p.n_split = 1;
+            if (items > 0 && items * 2 <= cap) {   // forced narrow on a small launch: the split as above
+                long long ns = n_cu / items;
+                if (ns < 2) ns = 2;
+                if (ns > g_max_split) ns = g_max_split;
+                if (ns > p.max_entries) ns = p.max_entries;
+                if (ns > 1) p.n_split = (int)ns;
+            }
+            (void)try_scored_ahead();
         }
     }
     // Which class (item % 8 = kv head % 8 when Hkv is a multiple of 8) a workgroup's claims start with.  Staying with

@@ -124,14 +124,14 @@ bool attention_uses_mfma(int rows_per_pass, int kv_dtype, int D) {
     return rows_per_pass > 1 && D <= 256;
 }
 
-int attention_stream_waves(bool mfma, int kv_dtype) { return stream_waves(mfma, kv_dtype == kI8); }
-int attention_score_waves(bool mfma, int kv_dtype, int D) {
-    const int all = stream_waves(mfma, kv_dtype == kI8) + sel_waves(mfma);
+int attention_stream_waves(bool mfma, int kv_dtype, bool narrow) { return stream_waves(mfma, kv_dtype == kI8, narrow); }
+int attention_score_waves(bool mfma, int kv_dtype, int D, bool narrow) {
+    const int all = stream_waves(mfma, kv_dtype == kI8, narrow) + sel_waves(mfma);
     if (mfma) return all;   // the streamers lend their V tile areas
     return D <= 128 ? all : (all < 5 ? all : 5);   // 8 / 16 KiB tiles: five of them, as much as nine 4 KiB ones
 }
-int attention_stage_bytes(bool mfma, int kv_dtype, int D) {
-    return (mfma ? sel_waves(true) : attention_score_waves(false, kv_dtype, D)) * score_stage_bytes(D);
+int attention_stage_bytes(bool mfma, int kv_dtype, int D, bool narrow) {
+    return (mfma ? sel_waves(true) : attention_score_waves(false, kv_dtype, D, narrow)) * score_stage_bytes(D);
 }
 int cent_stage_bytes(int D) { return kCentWaves * score_stage_bytes(D); }
 int assign_stage_bytes(int D) { return 4 * score_stage_bytes(D); }

@@ -177,6 +177,9 @@ struct AttnParams {
     unsigned* split_done;          // [items] arrival counters (workspace), zeroed before every launch
     float* split_partials;         // [items * n_split][rows_per_pass][D + 2] un-normalised states (workspace)
     unsigned long long* debug;     // diagnostic builds only: [grid][16 items][16 stamps], else null
+    // 1: the plain one-q-head kernel runs as two workgroups of four streamer waves per CU instead of one of eight (twice
+    // the selector waves per CU; taken for fused launches with many short items per workgroup)
+    int narrow;
     // waves of a workgroup that share the centroid pass of the first item (each needs an LDS tile of its own; the
     // other waves wait): all of them for head dims up to 128, fewer for longer rows (VALU form)
     int score_waves;
@@ -209,11 +212,11 @@ int device_cu_count();
 int attention_rows_per_pass(int G, int kv_dtype, int D);
 bool attention_uses_mfma(int rows_per_pass, int kv_dtype, int D);
 // Streamer waves per workgroup of the two kernel forms (sizes the state and V-tile areas in LDS).
-int attention_stream_waves(bool mfma, int kv_dtype);
+int attention_stream_waves(bool mfma, int kv_dtype, bool narrow);
 // LDS tiles through which the centroid pass turns memory order into matrix-core operand order: bytes at off_stage of
 // the attention kernels, and at the end of the dynamic LDS of the cent kernels.
-int attention_stage_bytes(bool mfma, int kv_dtype, int D);
-int attention_score_waves(bool mfma, int kv_dtype, int D);   // AttnParams::score_waves of a plan
+int attention_stage_bytes(bool mfma, int kv_dtype, int D, bool narrow);
+int attention_score_waves(bool mfma, int kv_dtype, int D, bool narrow);   // AttnParams::score_waves of a plan
 int cent_stage_bytes(int D);      // kCentWaves tiles
 int assign_stage_bytes(int D);    // 4 tiles
 

@@ -57,6 +57,7 @@ spfaSetPageCap = _sig("spfaSetPageCap", c_int, [c_int])
 spfaSetMaxSplit = _sig("spfaSetMaxSplit", c_int, [c_int64])
 spfaSetTailSharing = _sig("spfaSetTailSharing", c_int, [c_int])
 spfaSetSharedScoring = _sig("spfaSetSharedScoring", c_int, [c_int])
+spfaSetWorkgroupGeometry = _sig("spfaSetWorkgroupGeometry", c_int, [c_int])
 spfaSetPageSize = _sig("spfaSetPageSize", c_int, [c_int64])
 spfaSetActualSeqLengthsDevice = _sig("spfaSetActualSeqLengthsDevice", c_int, [c_void_p, c_int64])
 spfaSetTokenPositions = _sig("spfaSetTokenPositions", c_int, [c_int])

@@ -115,6 +115,10 @@ SPFA_API aclnnStatus spfaSetTailSharing(int enable);
  * multiple of the kv heads) every workgroup owns J sequences of one kv head and scores their J rows in one pass
  * before it streams the first.  Outputs do not depend on the setting.  0 turns both off.  Default on. */
 SPFA_API aclnnStatus spfaSetSharedScoring(int enable);
+/* Workgroup geometry of the one-q-head attention kernels: 1 = one workgroup of eight streamer waves per CU, 2 = two
+ * workgroups of four, 0 (default) = the planner's choice (eight, unless a fused launch hands a workgroup more items
+ * than can be scored ahead).  Outputs do not depend on it beyond fp32 rounding.  Stays until changed. */
+SPFA_API aclnnStatus spfaSetWorkgroupGeometry(int geometry);
 /* page size of the two ops without a blockSize attribute (CentSelect, SelectPosition); the reference
  * compiles in 128 (cent_select.cpp:17, select_position.cpp:112).  Default 128. */
 SPFA_API aclnnStatus spfaSetPageSize(int64_t pageSize);

@@ -382,3 +382,58 @@ def test_items_scored_ahead_equal_items_scored_one_by_one(H, B, kvdt):
     assert np.array_equal(plen.cpu().numpy(), wlen)
     assert np.array_equal(pmax.cpu().numpy(), wmax)
     assert float(parity.rel_err(H.f32(out), want).max()) <= TOL
+
+
+@pytest.mark.parametrize("B,kvdt", [(8, "f16"), (40, "f16"), (64, "i8"), (96, "f16")])
+def test_wide_and_narrow_workgroups_agree(H, B, kvdt):
+    """The one-q-head kernels exist as one workgroup of eight streamer waves per CU and as two of four; the planner
+    picks by launch shape (B = 96 x 32 heads is more than eight items per wide workgroup: narrow).  Both forced in turn,
+    with and without the items scored ahead: integer outputs bit for bit, the attention to fp32 rounding; the planner's
+    own choice against the oracle."""
+    from custom_ops import _abi
+    Hq = Hkv = 32
+    D, C, topk, bs, kv_page_len, max_page = 128, 128, 8, 32, 96, 40
+    rng = datagen.rng_for(950 + B)
+    seq_lens = [int(x) for x in rng.integers(1, max_page * bs, size=B)]
+    seq_lens[0], seq_lens[B - 1] = max_page * bs, 1
+    q, l1, ids, table, seq, k, v = _fusion_case(350 + B, B, Hq, Hkv, D, C, seq_lens, kv_page_len, max_page, bs,
+                                                kv="i8" if kvdt == "i8" else "f16")
+    kd, vd = (H.dev(k), H.dev(v)) if kvdt == "i8" else (H.dev(k, torch.float16), H.dev(v, torch.float16))
+    qd, l1d, td, idsd, seqd = H.dev(q, torch.float16), H.dev(l1, torch.float16), H.dev(table), H.dev(ids), H.dev(seq)
+    kw, okw = {}, {}
+    if kvdt == "i8":
+        a_s, a_o = datagen.antiquant_case(5, Hkv, D, True)
+        kw = dict(antiq_scale=H.dev(a_s), antiq_offset=H.dev(a_o))
+        okw = dict(antiquant_scale=a_s.astype(np.float32), antiquant_offset=a_o.astype(np.float32))
+    scale = D ** -0.5
+    auto = H.call_fusion(qd, kd, vd, td, l1d, idsd, seqd, Hq, Hkv, scale, bs, topk, out_dtype=torch.float32, **kw)
+    res = {}
+    try:
+        for geo in (1, 2):
+            for shared in (1, 0):
+                _abi.check(_abi.spfaSetWorkgroupGeometry(geo), "spfaSetWorkgroupGeometry")
+                _abi.check(_abi.spfaSetSharedScoring(shared), "spfaSetSharedScoring")
+                res[(geo, shared)] = H.call_fusion(qd, kd, vd, td, l1d, idsd, seqd, Hq, Hkv, scale, bs, topk,
+                                                   out_dtype=torch.float32, **kw)
+    finally:
+        _abi.spfaSetWorkgroupGeometry(0)
+        _abi.spfaSetSharedScoring(1)
+    big = float(auto[0].abs().max())
+    for key, r in res.items():
+        assert all(torch.equal(x, y) for x, y in zip(r[1:], auto[1:])), key
+        assert float((r[0] - auto[0]).abs().max()) <= 2e-6 * big, key
+    want, wpos, wlen, wmax = ref.sparse_paged_fusion_attention(q, k, v, table, l1, ids, seq, Hq, Hkv, scale, bs, topk, 256, **okw)
+    out, pos, plen, pmax = auto
+    assert np.array_equal(pos.cpu().numpy(), wpos) and np.array_equal(plen.cpu().numpy(), wlen)
+    assert np.array_equal(pmax.cpu().numpy(), wmax)
+    assert float(parity.rel_err(H.f32(out), want).max()) <= TOL
+    # lists given (the standalone op): both geometries as well
+    act = pmax[:, 0].contiguous()
+    outs = []
+    try:
+        for geo in (1, 2):
+            _abi.check(_abi.spfaSetWorkgroupGeometry(geo), "spfaSetWorkgroupGeometry")
+            outs.append(H.call_attention(qd, kd, vd, td, pos, act, Hq, Hkv, scale, bs, out_dtype=torch.float32, **kw))
+    finally:
+        _abi.spfaSetWorkgroupGeometry(0)
+    assert float((outs[0] - outs[1]).abs().max()) <= 2e-6 * big

@@ -22,22 +22,26 @@ TOL = 1e-3
 
 
 class _Knobs:
-    """Launch-planning knobs for one test: tail sharing forced on / off, page-list split off (all restored)."""
+    """Launch-planning knobs for one test: tail sharing forced on / off, page-list split off, the workgroup geometry of the
+    one-q-head kernels forced wide / narrow (all restored)."""
 
     def __init__(self, seed):
         self.tail = {3: 2, 6: 0}.get(seed % 8, 1)
         self.split = 1 if seed % 8 == 5 else (3 if seed % 8 == 1 else 16)
+        self.geometry = {0: 1, 1: 2, 2: 2}.get(seed % 5, 0)
 
     def __enter__(self):
         from custom_ops import _abi
         _abi.check(_abi.spfaSetTailSharing(self.tail), "spfaSetTailSharing")
         _abi.check(_abi.spfaSetMaxSplit(self.split), "spfaSetMaxSplit")
+        _abi.check(_abi.spfaSetWorkgroupGeometry(self.geometry), "spfaSetWorkgroupGeometry")
         return self
 
     def __exit__(self, *exc):
         from custom_ops import _abi
         _abi.spfaSetTailSharing(1)
         _abi.spfaSetMaxSplit(16)
+        _abi.spfaSetWorkgroupGeometry(0)
         return False
 
 
