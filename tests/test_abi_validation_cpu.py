@@ -245,3 +245,53 @@ def test_assign_block_ids_plan_and_mismatches(lib):
     ]:
         st, _, msg = call(**kw)
         assert st == PARAM_INVALID and fragment in msg, (kw.keys(), msg)
+
+
+def test_one_shot_extras_are_validated_and_consumed(lib):
+    """The operands that arrive through one-shot settings (softmax LSE output, shared prefix, antiquant mode): checked in
+    phase 1, and taken by the very next phase 1 whether it succeeds or fails."""
+    lib.spfaSetSoftmaxLseOut.argtypes = [c_void_p, c_int64]
+    lib.spfaSetSharedPrefix.argtypes = [c_void_p, c_void_p, c_int64, c_int64]
+    lib.spfaSetAntiquantMode.argtypes = [c_int64]
+    lib.spfaSetWorkgroupGeometry.argtypes = [c_int]
+    B, Hq = 3, 8
+    # LSE: too few values -> rejected; the next call (nothing armed) plans fine
+    assert lib.spfaSetSoftmaxLseOut(c_void_p(0x4000), B * Hq - 1) == 0
+    st, _, msg = attention(lib)
+    assert st == PARAM_INVALID and "softmax LSE output" in msg
+    assert attention(lib)[0] == 0
+    assert lib.spfaSetSoftmaxLseOut(c_void_p(0x4000), B * Hq) == 0
+    assert attention(lib)[0] == 0
+    # shared prefix: argument checks in the setter, plan checks in phase 1
+    assert lib.spfaSetSharedPrefix(c_void_p(0x5000), None, 64, 64) == PARAM_INVALID
+    assert lib.spfaSetSharedPrefix(c_void_p(0x5000), c_void_p(0x6000), 64, 65) == PARAM_INVALID
+    assert lib.spfaSetSharedPrefix(c_void_p(0x5008), c_void_p(0x6000), 64, 64) == 0
+    st, _, msg = attention(lib)
+    assert st == PARAM_INVALID and "16-byte aligned" in msg
+    assert lib.spfaSetSharedPrefix(c_void_p(0x5000), c_void_p(0x6000), 300, 200) == 0
+    st, ws_prefix, _ = attention(lib)
+    assert st == 0
+    assert attention(lib)[0] == 0                                   # consumed: no prefix any more
+    # a pseShift that covers sMax but not prefix + sMax
+    assert lib.spfaSetSharedPrefix(c_void_p(0x5000), c_void_p(0x6000), 300, 200) == 0
+    st, _, msg = attention(lib, pse=tensor(lib, (1, Hq, 1, 24 * 128), F16))
+    assert st == PARAM_INVALID and "prefix + sMax" in msg
+    # antiquant mode 1: float32 [2, B, S] parameters and an int8 cache
+    assert lib.spfaSetAntiquantMode(2) == PARAM_INVALID
+    assert lib.spfaSetAntiquantMode(1) == 0
+    st, _, msg = attention(lib)
+    assert st == PARAM_INVALID and "int8 KV cache" in msg
+    assert lib.spfaSetAntiquantMode(1) == 0
+    st, _, msg = attention(lib, kv_dtype=I8, antiq=tensor(lib, (2, 2, 128), F16))
+    assert st == PARAM_INVALID and "float32 [2, B, S]" in msg
+    assert lib.spfaSetAntiquantMode(1) == 0
+    st, _, msg = attention(lib, kv_dtype=I8, antiq=tensor(lib, (2, B, 24 * 128 - 1), F32))
+    assert st == PARAM_INVALID and "less than sMax" in msg
+    assert lib.spfaSetAntiquantMode(1) == 0
+    assert attention(lib, kv_dtype=I8, antiq=tensor(lib, (2, B, 24 * 128), F32))[0] == 0
+    assert attention(lib, kv_dtype=I8, antiq=tensor(lib, (2, 2, 128), F16))[0] == 0     # the mode was one-shot
+    # the geometry knob stays until changed and accepts 0, 1, 2 only
+    assert lib.spfaSetWorkgroupGeometry(3) == PARAM_INVALID
+    for g in (1, 2, 0):
+        assert lib.spfaSetWorkgroupGeometry(g) == 0
+        assert attention(lib)[0] == 0
