@@ -115,7 +115,8 @@ SENT = 0x7FFFFFFF
 @pytest.mark.parametrize("seed", range(int(os.environ.get("SPFA_FUZZ_SEEDS", "120")) // 2))
 def test_random_lists(seed):
     """sparse_paged_attention on given lists: both KV layouts, lists per q head or per kv head, sentinel-terminated
-    rows of any length (empty ones included), all forms of actual_seq_lengths, optional bias / mask / int8 output."""
+    rows of any length (empty ones included), all forms of actual_seq_lengths, optional bias / mask / int8 output,
+    shared prefix, per-token antiquant parameters; the softmax LSE of every launch is checked as well."""
     import gpu_helpers as H
     rng = datagen.rng_for(7000 + seed)
     kv = ["f16", "bf16", "i8"][seed % 3]
@@ -161,19 +162,57 @@ def test_random_lists(seed):
         mask = rng.random((B, S)) < 0.25
         kw.update(pse=H.dev(pse, tdt), mask=H.dev(mask))
         okw.update(pse_shift=pse, atten_mask=mask)
+    n_pre = 0
+    if seed % 4 == 3:      # a shared prefix in front of every list (its last run of block_size tokens partly filled)
+        n_pre = int(rng.integers(1, 3 * bs + 1))
+        s_pre = n_pre + int(rng.integers(0, 9))
+        if kv == "i8":
+            kp, vp = (rng.integers(-127, 128, size=(s_pre, Hkv, D)).astype(np.int8) for _ in range(2))
+        else:
+            kp, vp = (rng.standard_normal((s_pre, Hkv, D)).astype(np.float16) for _ in range(2))
+            if kv == "bf16":
+                kp, vp = (ref.round_to_bf16(x.astype(np.float32)) for x in (kp, vp))
+        if layout == "BSH":
+            kp, vp = kp.reshape(1, s_pre, Hkv * D), vp.reshape(1, s_pre, Hkv * D)
+        else:
+            kp, vp = (np.ascontiguousarray(x.transpose(1, 0, 2)).reshape(1, Hkv, s_pre, D) for x in (kp, vp))
+        cvp = (lambda a: H.dev(a)) if kv == "i8" else (lambda a: H.dev(a, tdt))
+        kw.update(key_shared_prefix=cvp(kp), value_shared_prefix=cvp(vp), actual_shared_prefix_len=n_pre)
+        okw.update(key_shared_prefix=kp, value_shared_prefix=vp, shared_prefix_len=n_pre)
+        if "pse" in kw:    # bias / mask columns start with the prefix tokens
+            S = max_page * bs + n_pre
+            pse = (rng.standard_normal((B, Hq, 1, S)) * 2).astype(np.float16)
+            if kv == "bf16":
+                pse = ref.round_to_bf16(pse.astype(np.float32))
+            mask = rng.random((B, S)) < 0.25
+            kw.update(pse=H.dev(pse, tdt), mask=H.dev(mask))
+            okw.update(pse_shift=pse, atten_mask=mask)
+    if kv == "i8" and seed % 5 == 4:      # per-token antiquant parameters over the same columns
+        S = max_page * bs + n_pre + int(rng.integers(0, 4))
+        sc = (rng.random((2, B, S)) * 0.02 + 0.002).astype(np.float32)
+        of = (rng.standard_normal((2, B, S)) * 4).astype(np.float32) if seed % 2 == 0 else None
+        kw.update(antiq_scale=H.dev(sc), antiq_offset=None if of is None else H.dev(of), antiquant_mode=1)
+        okw.update(antiquant_scale=sc, antiquant_offset=of, antiquant_mode=1)
     scale = D ** -0.5
-    want = ref.sparse_paged_attention(q, k, v, table, pos, act_host, Hq, Hkv, scale, bs, layout, **okw)
+    want, wlse = ref.sparse_paged_attention(q, k, v, table, pos, act_host, Hq, Hkv, scale, bs, layout, return_lse=True, **okw)
     kd, vd = (H.dev(k), H.dev(v)) if kv == "i8" else (H.dev(k, tdt), H.dev(v, tdt))
     args = (H.dev(q, tdt), kd, vd, H.dev(table), H.dev(pos), act_arg, Hq, Hkv, scale, bs)
+    lse = torch.full((B, Hq), 3.0, dtype=torch.float32, device=H.DEV)
     with _Knobs(seed):
-        out = H.f32(H.call_attention(*args, out_dtype=torch.float32, **kw))
-    info = dict(kv=kv, D=D, G=G, Hkv=Hkv, bs=bs, layout=layout, rows=rows, B=B, P=P, max_page=max_page, mode=mode)
+        out = H.f32(H.call_attention(*args, out_dtype=torch.float32, softmax_lse=lse, **kw))
+    info = dict(kv=kv, D=D, G=G, Hkv=Hkv, bs=bs, layout=layout, rows=rows, B=B, P=P, max_page=max_page, mode=mode,
+                n_pre=n_pre, per_token=okw.get("antiquant_mode", 0))
     err = float(parity.rel_err(out, want).max())
     assert err <= TOL, f"max rel err {err:.3e} {info}"
+    got_lse = lse.cpu().numpy()
+    live = wlse > -1e38
+    assert np.array_equal(got_lse[~live], wlse[~live]), info
+    lerr = np.abs(got_lse[live] - wlse[live])
+    assert (lerr <= 2e-4 + 2e-5 * np.abs(wlse[live])).all(), f"LSE max abs err {lerr.max():.3e} {info}"
     empty = (pos[:, :, 0] == SENT)
     for b in range(B):
         for h in range(Hq):
-            if empty[b, h if rows == Hq else h // G]:
+            if empty[b, h if rows == Hq else h // G] and not n_pre:
                 assert (out[b, h] == 0).all(), info
     if seed % 6 == 2:      # int8 output of the same launch
         sc = (rng.random(Hq * D) * 400 + 100).astype(np.float32)
