@@ -30,6 +30,20 @@ asc = wl["a_scale"] if wl["a_scale"] is not None else e
 aof = wl["a_off"] if wl["a_off"] is not None else e
 act = pmax[:, 0].contiguous()
 pages = int(plen[:, :, 0].sum().item()) if Hkv == Hq else None
+if Hkv != Hq:
+    # a group streams the UNION of its heads' lists in the fused op: hand the standalone op that union as one list per kv head
+    G = Hq // Hkv
+    SENT = 0x7FFFFFFF
+    flat = pos.view(B, Hkv, G * 256).to(torch.int64)
+    srt = flat.sort(dim=2).values
+    dup = torch.zeros_like(srt, dtype=torch.bool)
+    dup[:, :, 1:] = srt[:, :, 1:] == srt[:, :, :-1]
+    srt[dup] = SENT
+    srt = srt.sort(dim=2).values
+    n = int((srt != SENT).sum(dim=2).max().item())
+    pos = srt[:, :, :max(n, 1)].to(torch.int32).contiguous()
+    pages = int((pos != SENT).sum().item())
+    act = torch.full((B,), pos.shape[2] * bs, dtype=torch.int64, device=dev)
 
 
 def attn():

@@ -55,9 +55,23 @@ ei = torch.empty(0, dtype=torch.int64, device=dev)
 plan.run()
 torch.cuda.synchronize()
 act = pmax[:, 0].contiguous()
+if Hkv != Hq:   # the union of a group's lists, one list per kv head (what the fused op streams)
+    G = Hq // Hkv
+    SENT = 0x7FFFFFFF
+    srt = pos.view(B, Hkv, G * 256).to(torch.int64).sort(dim=2).values
+    dup = torch.zeros_like(srt, dtype=torch.bool)
+    dup[:, :, 1:] = srt[:, :, 1:] == srt[:, :, :-1]
+    srt[dup] = SENT
+    srt = srt.sort(dim=2).values
+    n = int((srt != SENT).sum(dim=2).max().item())
+    pos_attn = srt[:, :, :max(n, 1)].to(torch.int32).contiguous()
+    act = torch.full((B,), pos_attn.shape[2] * bs, dtype=torch.int64, device=dev)
+else:
+    pos_attn = pos
 try:
     d_attn = report("attention only", lambda: custom_ops.sparse_paged_attention(
-        wl["q"], wl["key"], wl["val"], e, e, act, e, e, e, e, e, e, e, wl["table"], ei, pos, Hq, D ** -0.5, "BNSD", Hkv, bs, 1))
+        wl["q"], wl["key"], wl["val"], e, e, act, e, e, e, e, e, wl["a_scale"] if wl["a_scale"] is not None else e,
+        wl["a_off"] if wl["a_off"] is not None else e, wl["table"], ei, pos_attn, Hq, D ** -0.5, "BNSD", Hkv, bs, 1))
 except RuntimeError:
     d_attn = np.zeros((1, 16, 16), dtype="int64")
 _ok = d_attn[:, 1, 8] > 0
@@ -71,6 +85,18 @@ for it in range(5):
     if ms.any():
         print(f"item#{it}: n={int(ms.sum())} stream={np.median(row[ms, 9] - row[ms, 8]):.0f} "
               f"first_start={np.median(row[ms, 8]) - d_attn[d_attn > 0].min():.0f}")
+_t15 = d_attn[:, 15, :]
+_okA = d_attn[:, 1, 8] > 0
+if _okA.any():
+    _st = d_attn[_okA, 1, 8]
+    _wend = d_attn[:, :15, 9].max(axis=1)[_okA]
+    _kend = np.where(_t15[_okA, 2] > 0, _t15[_okA, 2], _wend)
+    _n = (d_attn[:, 1:15, 8] > 0).sum(axis=1)[_okA]
+    print("attention only: items per workgroup " + " ".join(f"{k}:{int((_n == k).sum())}" for k in sorted(set(_n.tolist()))))
+    print("attention only: wave 0 done / loop exit / kernel end after first stream start (p0 p50 p100): " +
+          " ".join(f"{np.percentile(_wend - _st, q):.0f}" for q in (0, 50, 100)) + " / " +
+          (" ".join(f"{np.percentile(_t15[_okA, 0] - _st, q):.0f}" for q in (0, 50, 100)) if (_t15[_okA, 0] > 0).any() else "-") + " / " +
+          " ".join(f"{np.percentile(_kend - _st, q):.0f}" for q in (0, 50, 100)))
 d = report("fused", plan.run)
 row = d[:, 0, :]
 ok = row[:, 11] > 0
