@@ -388,3 +388,23 @@ def test_per_token_antiquant_errors(H):
     out = H.call_attention(q, kv8, kv8, table, pos, [128], Hq, Hq, 1.0, bs,
                            antiq_scale=H.dev(np.ones((2, Hq, D), np.float16)))
     assert torch.isfinite(out.float()).all()
+
+
+def test_per_token_antiquant_in_a_large_launch(H):
+    """More items than resident workgroups: per-token parameters follow the list slot through shared last items and the
+    rolling item pipeline (column = prefix tokens + slot * block_size + token)."""
+    Hq, D, bs, B, P = 32, 128, 32, 40, 128
+    rng, q, k, v, table, pos, act = _case(87, "i8", Hq, Hq, "kv", D, bs, B=B, n_blocks=64, max_page=24, P=P)
+    act = [P * bs] * B
+    kp, vp = _prefix(rng, "i8", 50, Hq, D, "BSH")
+    S = table.shape[1] * bs + 50
+    sc, of = _per_token_params(rng, B, S, True)
+    want, wlse = ref.sparse_paged_attention(q, k, v, table, pos, act, Hq, Hq, D ** -0.5, bs, "BSH", antiquant_scale=sc,
+                                            antiquant_offset=of, antiquant_mode=1, key_shared_prefix=kp,
+                                            value_shared_prefix=vp, return_lse=True)
+    lse = torch.empty((B, Hq), dtype=torch.float32, device=H.DEV)
+    out = H.call_attention(H.dev(q), H.dev(k), H.dev(v), H.dev(table), H.dev(pos), torch.tensor(act), Hq, Hq, D ** -0.5,
+                           bs, out_dtype=torch.float32, antiq_scale=H.dev(sc), antiq_offset=H.dev(of), antiquant_mode=1,
+                           softmax_lse=lse, key_shared_prefix=H.dev(kp), value_shared_prefix=H.dev(vp))
+    assert float(parity.rel_err(H.f32(out), want).max()) <= TOL
+    _lse_close(lse.cpu().numpy(), wlse)
