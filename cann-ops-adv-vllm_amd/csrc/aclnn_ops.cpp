@@ -187,11 +187,16 @@ int round_up(int x, int m) { return (x + m - 1) / m * m; }
 // q rows scored per centroid pass by the standalone scoring ops: the keys [rows][Cp] u32 and the eight waves' centroid
 // tiles share a 100 KiB budget (8 rows at C = 2048, D = 128: one row per wave), at most 16 rows (one MFMA tile).  When a whole group fits, rows of several sequences share the pass, dealt
 // evenly over the workgroups of a kv head.
-void plan_cent_rows(spfa::CentParams& p) {
+// aux_bytes: what the op keeps in LDS besides keys and tiles (sort buffers, cluster bitmaps); the keys take what is left
+// of the CU's LDS when that is less than the budget.
+void plan_cent_rows(spfa::CentParams& p, size_t aux_bytes) {
 #ifndef SPFA_CENT_BUDGET_KB
 #define SPFA_CENT_BUDGET_KB 100
 #endif
-    int r = (SPFA_CENT_BUDGET_KB * 1024 - spfa::cent_stage_bytes(p.D)) / (p.Cp * 4);
+    p.score_waves = spfa::cent_score_waves(p.D);
+    long long budget = SPFA_CENT_BUDGET_KB * 1024;
+    if (budget > (long long)kMaxLds - (long long)aux_bytes) budget = (long long)kMaxLds - (long long)aux_bytes;
+    int r = (int)((budget - spfa::cent_stage_bytes(p.D)) / ((long long)p.Cp * 4));
     if (r < 1) r = 1;
     if (r > 16) r = 16;
     if (p.G >= r) {                 // the group alone fills (or exceeds) a pass
@@ -390,11 +395,17 @@ aclnnStatus aclnnComputeCentGetWorkspaceSize(const aclTensor* query, const aclTe
     p.qk_dtype = to_dtype(query->dtype);
     p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.G = Hq / Hkv; p.D = D; p.C = C; p.k = k;
     p.Cp = round_up(C, 128);
-    plan_cent_rows(p);
     p.indices = (int32_t*)data_ptr(indicesOut);
     int npow2 = 64;
     while (npow2 < k) npow2 <<= 1;
-    p.lds_bytes = (size_t)p.rows_per_pass * p.Cp * 4 + (size_t)spfa::kCentWaves * npow2 * 8 + (size_t)spfa::cent_stage_bytes(p.D);
+    const size_t aux = (size_t)spfa::kCentWaves * npow2 * 8;   // one sort buffer per wave
+    plan_cent_rows(p, aux);
+    p.lds_bytes = (size_t)p.rows_per_pass * p.Cp * 4 + aux + (size_t)spfa::cent_stage_bytes(p.D);
+    if (p.lds_bytes > kMaxLds) {
+        delete e;
+        return fail(ACLNN_ERR_PARAM_INVALID, "compute_cent with %d clusters, k = %d, head dim %d needs %zu bytes of LDS (> %zu)", C, k, D,
+                    p.lds_bytes, kMaxLds);
+    }
     *workspaceSize = 0;
     *executor = e;
     return ACLNN_SUCCESS;
@@ -503,7 +514,8 @@ aclnnStatus aclnnCentSelectGetWorkspaceSize(const aclTensor* query, const aclTen
     p.qk_dtype = to_dtype(query->dtype);
     p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.G = Hq / Hkv; p.D = D; p.C = C; p.k = k;
     p.Cp = round_up(C, 128);
-    plan_cent_rows(p);
+    const size_t aux = (size_t)spfa::kCentWaves * (p.Cp / 32) * 4;   // one cluster bitmap per wave
+    plan_cent_rows(p, aux);
     p.block_ids = (const int32_t*)data_ptr(blockIds);
     p.block_table = (const int32_t*)data_ptr(blockTable);
     p.seq_len = (const int32_t*)data_ptr(seqLen);
@@ -513,7 +525,12 @@ aclnnStatus aclnnCentSelectGetWorkspaceSize(const aclTensor* query, const aclTen
     p.page_position = (int32_t*)data_ptr(pagePositionOut);
     p.page_position_length = (int32_t*)data_ptr(pagePositionLengthOut);
     p.max_page_position_length = (unsigned long long*)data_ptr(maxPagePositionLengthOut);
-    p.lds_bytes = (size_t)p.rows_per_pass * p.Cp * 4 + (size_t)spfa::kCentWaves * (p.Cp / 32) * 4 + (size_t)spfa::cent_stage_bytes(p.D);
+    p.lds_bytes = (size_t)p.rows_per_pass * p.Cp * 4 + aux + (size_t)spfa::cent_stage_bytes(p.D);
+    if (p.lds_bytes > kMaxLds) {
+        delete e;
+        return fail(ACLNN_ERR_PARAM_INVALID, "cent_select with %d clusters, head dim %d needs %zu bytes of LDS (> %zu)", C, D,
+                    p.lds_bytes, kMaxLds);
+    }
     *workspaceSize = 0;
     *executor = e;
     return ACLNN_SUCCESS;

@@ -133,7 +133,9 @@ int attention_score_waves(bool mfma, int kv_dtype, int D, bool narrow) {
 int attention_stage_bytes(bool mfma, int kv_dtype, int D, bool narrow) {
     return (mfma ? sel_waves(true) : attention_score_waves(false, kv_dtype, D, narrow)) * score_stage_bytes(D);
 }
-int cent_stage_bytes(int D) { return kCentWaves * score_stage_bytes(D); }
+// 4 KiB tiles (D <= 128): every wave; 8 / 16 KiB tiles: four / two waves, the same 33 KiB
+int cent_score_waves(int D) { return D <= 128 ? kCentWaves : (D <= 256 ? 4 : 2); }
+int cent_stage_bytes(int D) { return cent_score_waves(D) * score_stage_bytes(D); }
 int assign_stage_bytes(int D) { return 4 * score_stage_bytes(D); }
 
 int attention_rows_per_pass(int G, int kv_dtype, int D) {

@@ -23,6 +23,7 @@ struct CentParams {
     int qk_dtype;              // kF16 | kBF16
     int B, Hq, Hkv, G, D, C, k;
     int rows_per_pass;         // q rows scored per centroid pass (LDS budget of the keys, <= 16)
+    int score_waves;           // waves of the workgroup that share the centroid pass (one LDS tile each)
     int seq_per_group;         // sequences whose rows share one pass (rows_per_pass / G when G fits, else 1)
     int Cp;                    // C rounded up to 64
     // mode 0: compute_cent (sorted indices out)
@@ -217,7 +218,8 @@ int attention_stream_waves(bool mfma, int kv_dtype, bool narrow);
 // the attention kernels, and at the end of the dynamic LDS of the cent kernels.
 int attention_stage_bytes(bool mfma, int kv_dtype, int D, bool narrow);
 int attention_score_waves(bool mfma, int kv_dtype, int D, bool narrow);   // AttnParams::score_waves of a plan
-int cent_stage_bytes(int D);      // kCentWaves tiles
+int cent_score_waves(int D);     // waves that share the pass of the standalone scoring kernels
+int cent_stage_bytes(int D);      // their tiles
 int assign_stage_bytes(int D);    // 4 tiles
 
 }  // namespace spfa

@@ -28,6 +28,8 @@ def ops():
 @pytest.mark.parametrize("C,k,Hq,Hkv,D", [(4096, 64, 4, 2, 128), (16384, 33, 2, 2, 64), (2048, 100, 4, 4, 128),
                                            (2560, 8, 6, 2, 32),
                                            (512, 16, 4, 2, 512), (1024, 32, 4, 4, 512),    # the largest head dim
+                                           (640, 640, 8, 8, 512),    # ... with k = C: 1 KiB rows beside the largest sort buffers
+                                           (1024, 1000, 4, 2, 256),
                                            (100, 7, 6, 2, 32)])   # D = 32 scores 256 centroids per step, C pads to 128
 def test_large_cluster_counts(H, ops, C, k, Hq, Hkv, D):
     B, bs, pages = 5, 128, 40
