@@ -86,21 +86,42 @@ def test_random_shape(seed):
                    antiquant_offset=None if a_o is None else a_o.astype(np.float32))
     scale = D ** -0.5
     P = 256
-    want, wpos, wlen, wmax = ref.sparse_paged_fusion_attention(
+    n_pre = 0
+    if seed % 4 == 2:      # a shared prefix in front of every head's pages; the selection outputs do not know about it
+        rng = datagen.rng_for(11000 + seed)
+        n_pre = int(rng.integers(1, 2 * bs + 1))
+        if c["kv"] == "i8":
+            kp, vp = (rng.integers(-127, 128, size=(1, n_pre, Hkv * D)).astype(np.int8) for _ in range(2))
+        else:
+            kp, vp = (rng.standard_normal((1, n_pre, Hkv * D)).astype(np.float16) for _ in range(2))
+            if c["kv"] == "bf16":
+                kp, vp = (ref.round_to_bf16(x.astype(np.float32)) for x in (kp, vp))
+        cvp = (lambda a: H.dev(a)) if c["kv"] == "i8" else (lambda a: H.dev(a, tdt))
+        kw.update(key_shared_prefix=cvp(kp), value_shared_prefix=cvp(vp))
+        okw.update(key_shared_prefix=kp, value_shared_prefix=vp)
+    (want, wlse), wpos, wlen, wmax = ref.sparse_paged_fusion_attention(
         q, kc, vc, table, l1, ids, seq, Hq, Hkv, scale, bs, k, P, sink_recent=c["sink_recent"],
-        max_pages_cap=c["cap"], **okw)
+        max_pages_cap=c["cap"], return_lse=True, **okw)
     kd, vd = (H.dev(kc), H.dev(vc)) if c["kv"] == "i8" else (H.dev(kc, tdt), H.dev(vc, tdt))
     qd, l1d, td, idsd, seqd = H.dev(q, tdt), H.dev(l1, tdt), H.dev(table), H.dev(ids), H.dev(seq)
+    lse = torch.full((q.shape[0], Hq), 5.0, dtype=torch.float32, device=H.DEV)
     with _Knobs(seed) as knobs:
         out, pos, plen, pmax = H.call_fusion(qd, kd, vd, td, l1d, idsd, seqd, Hq, Hkv, scale, bs, k, P=P,
                                              out_dtype=torch.float32, sink_recent=c["sink_recent"],
-                                             max_pages_cap=c["cap"], **kw)
-    info = f"{c} tail_sharing={knobs.tail} max_split={knobs.split}"
+                                             max_pages_cap=c["cap"], softmax_lse=lse, **kw)
+    kw.pop("key_shared_prefix", None)
+    kw.pop("value_shared_prefix", None)
+    info = f"{c} tail_sharing={knobs.tail} max_split={knobs.split} geometry={knobs.geometry} n_pre={n_pre}"
     assert np.array_equal(pos.cpu().numpy(), wpos), info
     assert np.array_equal(plen.cpu().numpy(), wlen), info
     assert np.array_equal(pmax.cpu().numpy(), wmax), info
     err = float(parity.rel_err(H.f32(out)[:B], want).max())
     assert err <= TOL, f"max rel err {err:.3e} {info}"
+    got_lse = lse.cpu().numpy()[:B]
+    live = wlse > -1e38
+    assert np.array_equal(got_lse[~live], wlse[~live]), info
+    lerr = np.abs(got_lse[live] - wlse[live])
+    assert (lerr <= 2e-4 + 2e-5 * np.abs(wlse[live])).all(), f"LSE max abs err {lerr.max():.3e} {info}"
     # the separate ops on the same inputs (page size of cent_select is a knob; the reference compiles in 128)
     spos, slen, smax = custom_ops.cent_select(qd, l1d, idsd, td, seqd, k=k, sink_recent=c["sink_recent"],
                                               max_pages_cap=c["cap"], max_page_num=P, page_size=bs)
@@ -217,7 +238,10 @@ def test_random_lists(seed):
     if seed % 6 == 2:      # int8 output of the same launch
         sc = (rng.random(Hq * D) * 400 + 100).astype(np.float32)
         out8 = H.call_attention(*args, quant_scale2=H.dev(sc.reshape(1, Hq, 1, D)), **kw)
-        assert np.array_equal(out8.cpu().numpy().astype(np.float32), ref.post_quant(out, sc)), info
+        # two launches: their fp32 results agree to rounding only (which wave streams which page depends on timing), so
+        # a value that sits on a quantisation boundary may land one step apart — seen once in 10,000 draws
+        diff = np.abs(out8.cpu().numpy().astype(np.float32) - ref.post_quant(out, sc))
+        assert diff.max() <= 1 and (diff > 0).mean() < 1e-3, info
 
 
 @pytest.mark.parametrize("seed", range(max(4, int(os.environ.get("SPFA_FUZZ_SEEDS", "120")) // 6)))
