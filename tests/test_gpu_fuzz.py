@@ -325,3 +325,72 @@ def test_random_select_position(seed):
     assert (length[:B] == wlen[:, :, None]).all(), info
     w = wgather.shape[2]
     assert np.array_equal(gather[:B, :, :w], wgather), info
+
+
+@pytest.mark.parametrize("seed", range(max(4, int(os.environ.get("SPFA_FUZZ_SEEDS", "120")) // 6)))
+def test_random_assign(seed):
+    """AssignBlockIds on grid pages (every token of a page holds the same grid vector, so the page mean and its scores
+    are exact and the argmax is bit-exact): cluster counts off the tile size, every head dim, both layouts, random first
+    new page per sequence, the per-call page bound, ids of untouched pages kept."""
+    import test_gpu_assign as A
+    rng = datagen.rng_for(5000 + seed)
+    dt = ["f16", "bf16"][seed % 2]
+    D = int(rng.choice([32, 64, 128, 128, 256, 512]))
+    Hkv = int(rng.choice([1, 2, 3, 8]))
+    C = int(rng.choice([16, 100, 129, 256, 640, 1000, 2048]))
+    bs = int(rng.choice([16, 32, 48, 128]))
+    B = int(rng.integers(1, 9))
+    max_page = int(rng.integers(3, 24))
+    layout = ["BSH", "BNSD"][int(rng.integers(0, 2))]
+    max_new = int(rng.choice([0, 0, 1, 5]))
+    c = A._case(5000 + seed, B, Hkv, D, C, bs, max_page, layout, dt)
+    info = dict(dt=dt, D=D, Hkv=Hkv, C=C, bs=bs, B=B, max_page=max_page, layout=layout, max_new=max_new)
+    got = A._run(c, max_new=max_new)
+    want, _ = ref.assign_block_ids(c["k"], c["table"], c["seq"], c["first"], c["l1"], c["ids0"], bs, layout, max_new, dt=dt)
+    assert np.array_equal(got, want), info
+
+
+@pytest.mark.parametrize("seed", range(max(4, int(os.environ.get("SPFA_FUZZ_SEEDS", "120")) // 6)))
+def test_random_tokens(seed):
+    """Token-level lists: random sorted token subsets per row (own list per q head, or one per KV head), rows from one
+    token to the whole sequence, lengths that bound the lists, every KV dtype and both layouts."""
+    import custom_ops
+    import gpu_helpers as H
+    import test_gpu_tokens as T
+    rng = datagen.rng_for(6000 + seed)
+    kvdt = ["f16", "bf16", "i8"][seed % 3]
+    D = int(rng.choice([64, 128]))                               # the head dims token-level lists support
+    G = int(rng.choice([1, 1, 2, 4, 8]))
+    Hkv = int(rng.choice([1, 2, 3, 8]))
+    if G * Hkv > 32:
+        Hkv = 32 // G
+    Hq = G * Hkv
+    bs = int(rng.choice([32, 64, 128])) if kvdt == "i8" else int(rng.choice([16, 32, 48, 128]))
+    layout = ["BSH", "BNSD"][int(rng.integers(0, 2))]
+    B = int(rng.integers(1, 6))
+    max_page = int(rng.integers(1, 14))
+    max_tokens = int(rng.choice([1, 7, 64, 200, 513, 1024]))
+    rows = Hq if (G == 1 or rng.integers(0, 2)) else Hkv
+    n_blocks = min(B * max_page, 60) + 1
+    k, v, sc, off = T._pool(6000 + seed, n_blocks, bs, Hkv, D, layout, kvdt)
+    table = rng.integers(0, n_blocks, size=(B, max_page)).astype(np.int32)
+    seq_tokens = [int(x) for x in rng.integers(1, max_page * bs + 1, size=B)]
+    counts = [[int(rng.integers(1, min(max_tokens, seq_tokens[b]) + 1)) for _ in range(rows)] for b in range(B)]
+    counts[0][0] = min(max_tokens, seq_tokens[0])
+    tp = T._random_lists(rng, B, rows, max_tokens, seq_tokens, counts)
+    q = datagen.ref_rand_f16(rng, (B, Hq, D)).astype(np.float32)
+    if kvdt == "bf16":
+        q = ref.round_to_bf16(q)
+    qd, kd, vd = T._to_dev(q, kvdt if kvdt != "i8" else "f16", H), T._to_dev(k, kvdt, H), T._to_dev(v, kvdt, H)
+    e = H.empty(qd.dtype)
+    asc = T._to_dev(sc, "f16", H) if kvdt == "i8" else e
+    aof = T._to_dev(off, "f16", H) if kvdt == "i8" else e
+    lens = None if seed % 2 else [int(x) for x in rng.integers(1, max_tokens + 1, size=B)]
+    info = dict(kvdt=kvdt, D=D, G=G, Hkv=Hkv, bs=bs, layout=layout, B=B, max_page=max_page, max_tokens=max_tokens,
+                rows=rows, lens=lens)
+    with _Knobs(seed):
+        got = custom_ops.sparse_paged_attention(qd, kd, vd, e, e, lens, e, e, e, e, e, asc, aof, H.dev(table),
+                                                H.empty(torch.int64), H.dev(tp), Hq, D ** -0.5, "BNSD", Hkv, bs, 1,
+                                                out_dtype=torch.float32, token_level=True)
+    want = ref.sparse_paged_attention(q, k, v, table, tp, lens, Hq, Hkv, D ** -0.5, bs, layout, sc, off, token_level=True)
+    assert parity.rel_err(H.f32(got), want).max() <= TOL, info
