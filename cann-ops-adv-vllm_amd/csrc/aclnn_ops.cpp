@@ -813,7 +813,7 @@ static size_t carve_lds(spfa::AttnParams& p, size_t nq) {
     p.off_qst = (int)off;
     if (!mfma) off += align16((size_t)2 * nq * p.D * 4);                   // pre-scaled q rows (VALU streamer)
     p.off_hdr = (int)off;
-    off += 2 * 48 + 16 + 64;                                               // two item headers + 4 workgroup words + 16 pipeline words
+    off += 2 * 48 + 16 + 64 + 144;                                         // two item headers + 4 workgroup words + 16 pipeline words + chunk table
     p.off_vst = (int)off;
     if (mfma) off += sw * 32 * (p.D * 2 + 32);                             // V tile images of the streamer waves
     p.off_stage = (int)off;
@@ -957,8 +957,10 @@ static void plan_workspace(aclOpExecutor* e) {
     p.dyn_pages = g_tail_sharing ? 1 : 0;   // spfaSetTailSharing(0) asks for a reproducible summation order
     const uint64_t n_boards = p.tail_on ? (uint64_t)(cap > 0 ? cap : 2ll * n_cu) : 0;   // one per resident workgroup
     const uint64_t state_bytes = (uint64_t)p.rows_per_pass * (p.D + 2) * 4;
-    p.tail_chunks = p.rows_per_pass <= 4 ? 32 : 16;   // one state per chunk + the owner's: keep the wide ones fewer
-    p.tail_stride = (long long)up256(32 + (uint64_t)p.max_entries * 8 + (mfma ? 0 : (uint64_t)p.rows_per_pass * p.D * 4) + 16 +
+    // one state per chunk + the owner's: up to 64 chunks where that stays within 48 KiB per board, else 32 (16 for the
+    // wide states of a group pass)
+    p.tail_chunks = p.rows_per_pass <= 4 ? (int)std::max<uint64_t>(32, std::min<uint64_t>(64, (48u << 10) / state_bytes)) : 16;
+    p.tail_stride = (long long)up256(32 + 144 + (uint64_t)p.max_entries * 8 + (mfma ? 0 : (uint64_t)p.rows_per_pass * p.D * 4) + 16 +
                                      (uint64_t)(p.tail_chunks + 1) * state_bytes);
     // Shared first scoring (fused op with a page-list split): the workgroups of one item score its rows together.
     uint64_t n_groups = 0;

@@ -437,3 +437,56 @@ def test_wide_and_narrow_workgroups_agree(H, B, kvdt):
     finally:
         _abi.spfaSetWorkgroupGeometry(0)
     assert float((outs[0] - outs[1]).abs().max()) <= 2e-6 * big
+
+
+@pytest.mark.parametrize("dtype,layout,Hq,Hkv,D,bs,B,max_page,hi", [
+    ("f16", "BSH", 8, 8, 128, 128, 3, 40, 40),       # quarter pages of 32 tokens
+    ("f16", "BNSD", 4, 4, 128, 16, 3, 60, 60),       # pages of two steps: halves
+    ("f16", "BSH", 6, 2, 128, 48, 3, 30, 30),        # group of 3 through the VALU streamer; 48-token pages: halves
+    ("bf16", "BSH", 4, 4, 64, 256, 2, 20, 20),
+    ("i8", "BSH", 8, 8, 128, 128, 3, 40, 40),
+    ("i8", "BSH", 8, 2, 128, 64, 3, 40, 40),         # int8 group pass (MFMA streamer, 32-token tiles)
+    ("f16", "BSH", 32, 4, 128, 128, 2, 50, 50),      # group of 8: MFMA streamer
+    ("bf16", "BSH", 16, 2, 128, 48, 2, 30, 30),      # MFMA streamer, a page of one and a half tiles: whole pages
+    ("f16", "BSH", 2, 2, 128, 16, 1, 1500, 1500),    # lists far longer than the chunk count: chunks of several units
+    ("f16", "BSH", 4, 4, 512, 32, 2, 24, 24),
+])
+def test_shared_last_items_in_sub_page_chunks(H, dtype, layout, Hq, Hkv, D, bs, B, max_page, hi):
+    """The last item of every workgroup is streamed in chunks (down to quarter pages) that other workgroups may take:
+    forced on here for small launches, with ragged lengths (partly filled last pages), lists from one page to the
+    whole table, every KV dtype and both streamers; compared with the oracle and with the launch without sharing."""
+    from custom_ops import _abi
+    rng = datagen.rng_for(4321 + Hq * 5 + D + bs)
+    kvdt = "i8" if dtype == "i8" else "f16"
+    n_blocks = min(B * max_page, 200)
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float16
+    q = datagen.ref_rand_f16(rng, (B, Hq, D))
+    k, v = datagen.kv_case(9, n_blocks, bs, Hkv, D, layout, dist="randn", dtype=kvdt)
+    sc = off = None
+    if dtype == "i8":
+        sc, off = datagen.antiquant_case(9, Hkv, D)
+    if dtype == "bf16":
+        q, k, v = (ref.round_to_bf16(x.astype(np.float32)) for x in (q, k, v))
+    table = rng.integers(0, n_blocks, size=(B, max_page)).astype(np.int32)
+    pos = _random_lists(rng, B, Hkv, max_page, hi, 1, hi)
+    pos[0, 0, :] = np.arange(hi, dtype=np.int32)                                          # a full list
+    act = [int(x) for x in rng.integers(1, hi * bs + 1, size=B)]
+    act[0] = hi * bs - 1                                                                  # all but one token
+    scale = 1.0 / np.sqrt(D)
+    want = ref.sparse_paged_attention(q, k, v, table, pos, act, Hq, Hkv, scale, bs, layout, sc, off)
+    qd = H.dev(q, tdt)
+    kd, vd = (H.dev(x) if dtype == "i8" else H.dev(x, tdt) for x in (k, v))
+    kw = dict(antiq_scale=H.dev(sc, tdt), antiq_offset=H.dev(off, tdt)) if dtype == "i8" else {}
+    outs = {}
+    _abi.check(_abi.spfaSetMaxSplit(1), "spfaSetMaxSplit")
+    try:
+        for tail in (0, 2, 2):
+            _abi.check(_abi.spfaSetTailSharing(tail), "spfaSetTailSharing")
+            out = H.f32(H.call_attention(qd, kd, vd, H.dev(table), H.dev(pos), torch.tensor(act, dtype=torch.int64),
+                                         Hq, Hkv, scale, bs, out_dtype=torch.float32, **kw))
+            assert float(parity.rel_err(out, want).max()) <= TOL, tail
+            outs.setdefault(tail, out)
+    finally:
+        _abi.spfaSetTailSharing(1)
+        _abi.spfaSetMaxSplit(16)
+    assert float(np.abs(outs[2] - outs[0]).max()) <= 4e-6 * float(np.abs(outs[0]).max())

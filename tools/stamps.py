@@ -114,10 +114,10 @@ print("duration by blockIdx % 8 (mean, min, max): " + " | ".join(
     f"{c}: {ends[idx % 8 == c].mean():.0f} {ends[idx % 8 == c].min():.0f} {ends[idx % 8 == c].max():.0f}" for c in range(8)))
 half = len(idx) // 2
 print(f"first half of the grid mean {ends[idx < half].mean():.0f}, second half {ends[idx >= half].mean():.0f}")
-per_item = d[:, 1:6, 9] - d[:, 1:6, 8]
-print("stream ticks by item position (median): " + " ".join(f"{np.median(per_item[ok, j][per_item[ok, j] > 0]):.0f}" for j in range(5) if (per_item[ok, j] > 0).any()))
-gaps = d[:, 2:6, 8] - d[:, 1:5, 9]
-print("wave 0 gap between items (median): " + " ".join(f"{np.median(gaps[ok, j][(d[ok, 2 + j, 8] > 0)]):.0f}" for j in range(4) if (d[ok, 2 + j, 8] > 0).any()))
+per_item = d[:, 1:10, 9] - d[:, 1:10, 8]
+print("stream ticks by item position (median): " + " ".join(f"{np.median(per_item[ok, j][per_item[ok, j] > 0]):.0f}" for j in range(9) if (per_item[ok, j] > 0).any()))
+gaps = d[:, 2:10, 8] - d[:, 1:9, 9]
+print("wave 0 gap between items (median): " + " ".join(f"{np.median(gaps[ok, j][(d[ok, 2 + j, 8] > 0)]):.0f}" for j in range(8) if (d[ok, 2 + j, 8] > 0).any()))
 t15 = d[:, 15, :]
 if (t15[ok, 0] > 0).any():
     print(f"tail: loop exit -> own arrival {np.median(t15[ok, 1] - t15[ok, 0]):.0f}, helping {np.median(t15[ok, 2] - t15[ok, 1]):.0f} "
