@@ -123,6 +123,8 @@ if (t15[ok, 0] > 0).any():
     print(f"tail: loop exit -> own arrival {np.median(t15[ok, 1] - t15[ok, 0]):.0f}, helping {np.median(t15[ok, 2] - t15[ok, 1]):.0f} "
           f"(max {np.max(t15[ok, 2] - t15[ok, 1]):.0f}) ticks; passes p50/max {np.median(t15[ok, 3]):.0f}/{t15[ok, 3].max()}; "
           f"chunks helped total {t15[ok, 4].sum()}, per wg max {t15[ok, 4].max()}")
+    print("tail: helping time by phase, median over workgroups (ticks): scan %.0f, copy %.0f, stream %.0f, state + arrival %.0f; "
+          "productive visits %.1f" % tuple(np.median(t15[ok, 6 + i]) for i in range(5)))
     print(f"tail: loop exit relative to own start p0/p50/p100: " + " ".join(f"{np.percentile(t15[ok, 0] - row[ok, 11], q):.0f}" for q in (0, 50, 100)))
     print(f"tail: kernel end relative to own start p0/p50/p100: " + " ".join(f"{np.percentile(t15[ok, 2] - row[ok, 11], q):.0f}" for q in (0, 50, 100)))
 n_items = (d[:, 1:15, 8] > 0).sum(axis=1)[ok]
