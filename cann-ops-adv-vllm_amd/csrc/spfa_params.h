@@ -167,7 +167,7 @@ struct AttnParams {
     int n_split;
     // sharing of every workgroup's last item (n_split == 1 only): boards and their data areas in the workspace
     int tail_on;
-    int tail_chunks;               // chunks a shared item is cut into (<= 32)
+    int tail_chunks;               // chunks a shared item is cut into (<= 64)
     void* tail_boards;             // [2 * #CU] 16-byte boards, zeroed before every launch
     char* tail_data;               // [2 * #CU] data areas of tail_stride bytes
     long long tail_stride;
