@@ -50,7 +50,7 @@ def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=50)   # the first ~50 launches of a process average 4 us more than the rest
     ap.add_argument("--batch", type=int, default=64, help="sequences per GPU")
     ap.add_argument("--heads", type=int, default=32)
     ap.add_argument("--kv-heads", type=int, default=32)
