@@ -69,6 +69,11 @@ def parse(argv=None):
     ap.add_argument("--no-tail-sharing", action="store_true", help="diagnostic: spfaSetTailSharing(0)")
     ap.add_argument("--force-tail-sharing", action="store_true", help="diagnostic: spfaSetTailSharing(2)")
     ap.add_argument("--no-shared-scoring", action="store_true", help="diagnostic: spfaSetSharedScoring(0)")
+    ap.add_argument("--allreduce-every", type=int, default=1,
+                    help="multi-GPU: all-reduce the global max_page_position_length every N-th step (0: never)")
+    ap.add_argument("--no-dropin", action="store_true",
+                    help="skip the extra leg that times the reference-shaped call (custom_ops.sparse_paged_fusion_attention: "
+                         "new descriptors, phase 1 and a new workspace on every call) beside the prepared launch")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default=None,
                     help="preset shape: c3 = BASELINE configs[2] (the default shape), c4 = configs[3] (int8 KV, S=64k), "
                          "c5 = configs[4] (GQA 32/8, S=128k, k=64; 64 sequences per GPU, 512 in all on 8 GPUs)")
@@ -249,14 +254,55 @@ def measured_traffic(key):
     return ent.get("hbm_bytes_per_launch"), "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes, same sources"
 
 
-def launch_ranks(a):
+def visible_gpu_count(sysfs="/sys/class/kfd/kfd/topology/nodes", dri="/dev/dri", environ=None):
+    """GPUs this process could use, found WITHOUT the HIP runtime (a process that has initialised the GPU must not
+    start the ranks): the KFD topology in sysfs lists one node per agent, GPUs are the nodes with simd_count > 0, and in a
+    container a GPU counts only when its render node is present under /dev/dri.  HIP_VISIBLE_DEVICES /
+    ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES narrow the count like they narrow the runtime's view.  Returns None when
+    the topology cannot be read (the ranks then find out for themselves)."""
+    environ = os.environ if environ is None else environ
+    try:
+        nodes = sorted(os.listdir(sysfs), key=lambda x: int(x) if x.isdigit() else 1 << 30)
+    except OSError:
+        return None
+    have_dri = os.path.isdir(dri)
+    n = 0
+    for node in nodes:
+        props = {}
+        try:
+            with open(os.path.join(sysfs, node, "properties")) as f:
+                for line in f:
+                    parts = line.split()
+                    if len(parts) == 2:
+                        props[parts[0]] = parts[1]
+        except OSError:
+            continue
+        try:
+            if int(props.get("simd_count", "0")) <= 0:
+                continue
+            minor = int(props.get("drm_render_minor", "-1"))
+        except ValueError:
+            continue
+        if have_dri and minor >= 0 and not os.path.exists(os.path.join(dri, f"renderD{minor}")):
+            continue
+        n += 1
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        val = environ.get(var)
+        if val is not None:
+            listed = [x for x in val.split(",") if x.strip() != ""]
+            n = min(n, len(listed))
+    return n
+
+
+def launch_ranks(a, argv=None):
     """Parent of a multi-GPU run started as plain `python bench.py --gpus N`: start one rank per GPU under
-    torch.distributed.run and return their exit status.  This process never creates a GPU context (counting the
-    devices does not), so nothing that has touched the GPU is ever replaced or forked."""
+    torch.distributed.run and return their exit status.  This process never touches the HIP runtime — the devices are
+    counted from sysfs — so nothing that has initialised the GPU is ever replaced or forked; the ranks are fresh
+    processes, and any rank that fails makes the whole run fail."""
     import socket
     import subprocess
-    n_dev = torch.cuda.device_count()
-    if n_dev < a.gpus and os.environ.get("BENCH_SINGLE_DEVICE") != "1":
+    n_dev = visible_gpu_count()
+    if n_dev is not None and n_dev < a.gpus and os.environ.get("BENCH_SINGLE_DEVICE") != "1":
         print(f"bench.py: --gpus {a.gpus} needs {a.gpus} visible GPUs but this machine shows {n_dev}; "
               "nothing was run (BENCH_SINGLE_DEVICE=1 BENCH_DIST_BACKEND=gloo rehearses the ranks on one device)",
               file=sys.stderr)
@@ -267,8 +313,51 @@ def launch_ranks(a):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + \
+        (sys.argv[1:] if argv is None else list(argv))
     return subprocess.call(cmd, env=env)
+
+
+def dropin_leg(a, wl, custom_ops, _abi, pos, plen, pmax, prepared_out):
+    """The reference-shaped call beside the prepared launch: custom_ops.sparse_paged_fusion_attention with the
+    reference's positional arguments — descriptors, phase 1 (validation + planning), a workspace from the allocator,
+    phase 2 and the destruction of everything, on every call, as extension/csrc/add_custom.cpp:770-935 does.
+    ms_per_step: the K calls between two events on the launch stream; host_ms_per_call: what the calling thread spends
+    per call (it only enqueues); kernels_per_call: from the library's own launch count."""
+    dev = wl["q"].device
+    e = torch.empty(0, dtype=wl["q"].dtype, device=dev)
+    e64 = torch.empty(0, dtype=torch.int64, device=dev)
+    hint = [max(1, a.seqlen // 8)]
+    scale = a.head_dim ** -0.5
+
+    def call():
+        return custom_ops.sparse_paged_fusion_attention(
+            wl["q"], wl["key"], wl["val"], e, e, hint, e, e, e, e, e,
+            wl["a_scale"] if wl["a_scale"] is not None else e, wl["a_off"] if wl["a_off"] is not None else e,
+            wl["table"], e64, wl["l1"], wl["block_ids"], wl["seq"], pos, plen, pmax,
+            a.heads, scale, "BNSD", a.kv_heads, a.block_size, 1, k=a.topk)[0]
+
+    torch.cuda.synchronize()
+    pos_prepared = pos.clone()
+    for _ in range(max(5, a.warmup // 5)):
+        out = call()
+    torch.cuda.synchronize()
+    same = bool(torch.equal(pos, pos_prepared)) and float((out.float() - prepared_out.float()).abs().max()) <= \
+        2e-3 * float(prepared_out.float().abs().max())
+    n0 = int(_abi.spfaKernelLaunches())
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        call()
+    host = time.perf_counter() - t0
+    ev1.record()
+    torch.cuda.synchronize()
+    n1 = int(_abi.spfaKernelLaunches())
+    return {"ms_per_step": ev0.elapsed_time(ev1) / a.steps, "host_ms_per_call": 1e3 * host / a.steps,
+            "kernels_per_call": (n1 - n0) / a.steps, "agrees_with_prepared": same,
+            "what": "custom_ops.sparse_paged_fusion_attention(...) with the reference's positional arguments: new "
+                    "descriptors, phase 1, a new workspace and phase 2 on every call"}
 
 
 def main():
@@ -318,7 +407,7 @@ def main():
     plan = custom_ops.PreparedFusion(wl["q"], wl["key"], wl["val"], wl["table"], wl["l1"], wl["block_ids"], wl["seq"],
                                      pos, plen, pmax, Hq, D ** -0.5, Hkv, bs, antiquant_scale=wl["a_scale"],
                                      antiquant_offset=wl["a_off"], k=a.topk)
-    reducer = shard.GlobalMaxLength(device) if world > 1 else None
+    reducer = shard.GlobalMaxLength(device, every=a.allreduce_every) if world > 1 else None
 
     def step():
         if reducer is not None:
@@ -391,7 +480,8 @@ def main():
         "ranks": {"world_size": world, "backend": {"nccl": "rccl"}.get(backend, backend),
                   "ranks_seen": (dist.get_world_size() if dist is not None else 1),
                   "kernel_ms_per_rank": rank_kernel_ms,
-                  "collective": ("all_reduce(MAX) of one int64 per step on a side stream" if world > 1 else "none")},
+                  "collective": ((f"all_reduce(MAX) of one int64 every {a.allreduce_every} step(s) on a side stream"
+                                  if a.allreduce_every > 0 else "none (--allreduce-every 0)") if world > 1 else "none")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                      "kernel_ms": kernel_ms,
@@ -403,6 +493,16 @@ def main():
                                                  "two events around the timed region, is lower than this median)"},
                      "algorithmic_bytes_per_launch": gbytes, "scope": "one GPU (rank 0)"},
     }
+    if world > 1:
+        result["ranks"]["allreduce_every"] = a.allreduce_every
+        result["ranks"]["collectives_submitted"] = reducer.submitted
+        result["ranks"]["collective_ms"] = reducer.collective_ms()   # rank 0's, events on the collective's stream
+    if rank == 0 and world == 1 and not a.no_dropin:
+        try:
+            result["dropin"] = dropin_leg(a, wl, custom_ops, _abi, pos, plen, pmax, plan.out.clone())
+            result["dropin"]["vs_prepared"] = result["dropin"]["ms_per_step"] / kernel_ms
+        except Exception as e:
+            result["dropin"] = {"ms_per_step": None, "error": repr(e)}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
             result["cpu_baseline"] = cpu_baseline(a, wl, custom_ops, {"out": plan.out, "pos": pos})

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -62,6 +63,7 @@ thread_local int g_page_cap = 0;
 thread_local int g_max_split = 16;
 thread_local int g_tail_sharing = 1;
 thread_local int g_shared_scoring = 1;
+thread_local int g_stream_slots = 1;       // 1: launches may keep their counters in library-owned per-stream slots
 thread_local int g_geometry = 0;           // 0: planner's choice, 1: wide, 2: narrow workgroups of the one-q-head kernels
 thread_local int64_t g_page_size = 128;   // PAGESIZE of cent_select.cpp:17 / select_position.cpp:112
 thread_local const long long* g_act_seq_dev = nullptr;   // one-shot, consumed by the next attention plan
@@ -328,6 +330,7 @@ aclnnStatus spfaSetWorkgroupGeometry(int geometry) {
     g_geometry = geometry;
     return ACLNN_SUCCESS;
 }
+aclnnStatus spfaSetLibraryCounters(int enable) { g_stream_slots = enable ? 1 : 0; return ACLNN_SUCCESS; }
 aclnnStatus spfaSetPageSize(int64_t page_size) {
     if (page_size < 1 || page_size > 512) return fail(ACLNN_ERR_PARAM_INVALID, "page size %lld out of [1, 512]", (long long)page_size);
     g_page_size = page_size;
@@ -368,6 +371,7 @@ aclnnStatus spfaSetWorkspacePersistent(aclOpExecutor* e, int enable) {
 }
 // Diagnostic only: device buffer of >= grid*16*16 uint64 that -DSPFA_STAMPS builds fill with cycle stamps.
 __attribute__((visibility("default"))) aclnnStatus spfaSetDebugBuffer(void* dev) { g_debug_buf = dev; return ACLNN_SUCCESS; }
+uint64_t spfaKernelLaunches(void) { return spfa::launches_so_far(); }
 const char* spfaVersion(void) { return "spfa-hip-gfx950 0.1"; }
 
 // ------------------------------------------------------------------------------------------------
@@ -398,8 +402,11 @@ aclnnStatus aclnnComputeCentGetWorkspaceSize(const aclTensor* query, const aclTe
     p.indices = (int32_t*)data_ptr(indicesOut);
     int npow2 = 64;
     while (npow2 < k) npow2 <<= 1;
-    const size_t aux = (size_t)spfa::kCentWaves * npow2 * 8;   // one sort buffer per wave
+    size_t aux = (size_t)spfa::kCentWaves * npow2 * 8;   // one sort buffer per wave
     plan_cent_rows(p, aux);
+    // wave w sorts rows w, w + kCentWaves, ...: a pass of fewer rows than waves (many clusters: one 64 KiB key row at
+    // C = 16384) needs that many buffers only
+    if (p.rows_per_pass < spfa::kCentWaves) aux = (size_t)p.rows_per_pass * npow2 * 8;
     p.lds_bytes = (size_t)p.rows_per_pass * p.Cp * 4 + aux + (size_t)spfa::cent_stage_bytes(p.D);
     if (p.lds_bytes > kMaxLds) {
         delete e;
@@ -514,8 +521,9 @@ aclnnStatus aclnnCentSelectGetWorkspaceSize(const aclTensor* query, const aclTen
     p.qk_dtype = to_dtype(query->dtype);
     p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.G = Hq / Hkv; p.D = D; p.C = C; p.k = k;
     p.Cp = round_up(C, 128);
-    const size_t aux = (size_t)spfa::kCentWaves * (p.Cp / 32) * 4;   // one cluster bitmap per wave
+    size_t aux = (size_t)spfa::kCentWaves * (p.Cp / 32) * 4;   // one cluster bitmap per wave
     plan_cent_rows(p, aux);
+    if (p.rows_per_pass < spfa::kCentWaves) aux = (size_t)p.rows_per_pass * (p.Cp / 32) * 4;   // (a wave per row of the pass)
     p.block_ids = (const int32_t*)data_ptr(blockIds);
     p.block_table = (const int32_t*)data_ptr(blockTable);
     p.seq_len = (const int32_t*)data_ptr(seqLen);
@@ -979,22 +987,100 @@ static void plan_workspace(aclOpExecutor* e) {
     e->ws_bytes = e->ws_lengths_off + (e->act_seq.empty() ? 0 : up256((uint64_t)p.B * 8));
 }
 
-// Bind the planned workspace layout to the caller's buffer and (zero: unless the buffer is known to be in the state
-// the previous launch left it in) enqueue the zeroing of its counters.
-static hipError_t bind_workspace(const aclOpExecutor* e, spfa::AttnParams& p, void* workspace, hipStream_t stream, bool zero) {
-    if (((uintptr_t)workspace & 15) != 0) return hipErrorInvalidValue;   // 64-bit atomics and 16-byte boards live in it
+// Bind the planned workspace layout: the part every launch expects zeroed (counters, arrival words, boards) at
+// zero_base, the data areas (partial states, shared page lists, exchanged keys, lengths) at the offsets phase 1 reported
+// from data_base.  Both are the caller's workspace unless the zeroed part lives in library-owned memory.  zero: enqueue
+// the zeroing of that part first (needed unless it is known to be in the state the previous launch left it in).
+static hipError_t bind_workspace(const aclOpExecutor* e, spfa::AttnParams& p, void* zero_base, void* data_base,
+                                 hipStream_t stream, bool zero) {
+    if ((((uintptr_t)zero_base | (uintptr_t)data_base) & 15) != 0) return hipErrorInvalidValue;   // 64-bit atomics, 16-byte boards
     auto up256 = [](uint64_t x) { return (x + 255) & ~255ull; };
-    p.counters = (unsigned*)workspace;
+    char* const zb = (char*)zero_base;
+    char* const db = (char*)data_base;
+    p.counters = (unsigned*)zb;
     p.zero_words = e->ws_zero_bytes / 8;
-    p.split_done = (unsigned*)((char*)workspace + kCounterBytes);
-    p.split_partials = (float*)((char*)workspace + e->ws_parts_off);
-    p.tail_boards = (char*)workspace + e->ws_boards_off;
-    p.tail_data = (char*)workspace + e->ws_tail_off;
-    p.pg_done = (unsigned*)((char*)workspace + e->ws_pgdone_off);
-    p.pg_keys = (uint32_t*)((char*)workspace + e->ws_pgkeys_off);
-    p.batch_arrive = (unsigned*)((char*)workspace + e->ws_batch_off);
-    p.batch_max = (unsigned long long*)((char*)workspace + e->ws_batch_off + up256((uint64_t)p.B * 4));
-    return zero ? spfa::launch_zero(workspace, e->ws_zero_bytes, nullptr, 0, stream) : hipSuccess;
+    p.split_done = (unsigned*)(zb + kCounterBytes);
+    p.tail_boards = zb + e->ws_boards_off;
+    p.pg_done = (unsigned*)(zb + e->ws_pgdone_off);
+    p.batch_arrive = (unsigned*)(zb + e->ws_batch_off);
+    p.batch_max = (unsigned long long*)(zb + e->ws_batch_off + up256((uint64_t)p.B * 4));
+    p.split_partials = (float*)(db + e->ws_parts_off);
+    p.tail_data = db + e->ws_tail_off;
+    p.pg_keys = (uint32_t*)(db + e->ws_pgkeys_off);
+    return zero ? spfa::launch_zero(zero_base, e->ws_zero_bytes, nullptr, 0, stream) : hipSuccess;
+}
+
+static bool stream_is_capturing(hipStream_t stream) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return st != hipStreamCaptureStatusNone;
+}
+
+// Library-owned counters.  The zeroed part of a workspace is small (a few KiB) but a caller's buffer cannot be trusted to
+// hold zeros, so a launch on it is two kernels.  Launches on ONE stream are ordered, and every launch leaves its
+// counters zeroed: so each (device, stream) pair is given a 64 KiB slot of the library's own device array, zeroed once
+// and then kept clean by the launches themselves, and a launch whose zeroed part fits runs as one kernel with only its
+// data areas in the caller's workspace.  Not under stream capture (a graph may be replayed on any stream), not on the
+// per-thread default stream handle (one handle, many streams); when the slots are used up the caller's workspace and
+// the zeroing kernel are used as before.
+struct StreamSlot { uintptr_t key; bool zeroed; };
+static StreamSlot g_slots[spfa::kMaxScratchDevices][spfa::kScratchSlots];
+static bool g_noalloc_zeroed[spfa::kMaxScratchDevices];
+static std::mutex g_slot_mutex;
+
+// The slot of (current device, stream) as a device address, or nullptr.  *needs_zero: first use of the slot.
+static void* stream_slot(hipStream_t stream, uint64_t zero_bytes, bool* needs_zero) {
+    if (!g_stream_slots || zero_bytes > spfa::kScratchSlotBytes) return nullptr;
+    if (stream == hipStreamPerThread || stream == hipStreamLegacy) return nullptr;
+    void* base = nullptr;
+    int dev = -1;
+    if (spfa::static_scratch(&base, &dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (dev < 0 || dev >= spfa::kMaxScratchDevices) return nullptr;
+    const uintptr_t key = (uintptr_t)stream + 1;   // 0 marks a free slot; the null stream is a stream like any other
+    std::lock_guard<std::mutex> lock(g_slot_mutex);
+    for (int i = 0; i < spfa::kScratchSlots; ++i) {
+        StreamSlot& s = g_slots[dev][i];
+        if (s.key == 0) { s.key = key; s.zeroed = false; }
+        if (s.key == key) {
+            *needs_zero = !s.zeroed;
+            s.zeroed = true;   // the zeroing is enqueued on this stream in front of the first launch that uses the slot
+            return (char*)base + spfa::kScratchSlotsOff + (size_t)i * spfa::kScratchSlotBytes;
+        }
+    }
+    return nullptr;
+}
+// a failed enqueue leaves the slot in an unknown state: zero it again next time
+static void stream_slot_failed(hipStream_t stream) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= spfa::kMaxScratchDevices) return;
+    const uintptr_t key = (uintptr_t)stream + 1;
+    std::lock_guard<std::mutex> lock(g_slot_mutex);
+    for (int i = 0; i < spfa::kScratchSlots; ++i)
+        if (g_slots[dev][i].key == key) g_slots[dev][i].zeroed = false;
+}
+
+// Where the zeroed part of this launch lives and whether it has to be zeroed first.
+struct ZeroPlace { void* base; bool zero; bool slot; };
+static ZeroPlace place_zeroed_part(aclOpExecutor* e, void* workspace, hipStream_t stream) {
+    // Under capture nothing runs now: the bookkeeping below describes enqueued work, so it is neither consulted beyond
+    // "this executor owns the workspace and has run on it" nor updated, and a replay zeroes for itself otherwise.
+    if (stream_is_capturing(stream)) {
+        const bool known_clean = e->repeatable && e->persistent_ws && e->clean_ws == workspace;
+        return ZeroPlace{workspace, !known_clean, false};
+    }
+    if (e->repeatable && e->persistent_ws) {
+        const bool known_clean = e->clean_ws == workspace;
+        e->clean_ws = workspace;
+        return ZeroPlace{workspace, !known_clean, false};
+    }
+    bool needs_zero = false;
+    if (void* slot = stream_slot(stream, e->ws_zero_bytes, &needs_zero)) return ZeroPlace{slot, needs_zero, true};
+    return ZeroPlace{workspace, true, false};
+}
+static void launch_outcome(aclOpExecutor* e, const ZeroPlace& z, hipStream_t stream, hipError_t err) {
+    if (err == hipSuccess) return;
+    if (z.slot) stream_slot_failed(stream);
+    else if (e->repeatable) e->clean_ws = nullptr;
 }
 
 // Phase 2 runs on the device phase 1 planned for (grid size, LDS limit and residency belong to that device).
@@ -1103,7 +1189,8 @@ aclnnStatus aclnnSparsePagedAttention(void* workspace, uint64_t workspaceSize, a
         const aclnnStatus ds = check_device(executor);
         if (ds != ACLNN_SUCCESS) { if (!executor->repeatable) delete executor; return ds; }
     }
-    hipError_t err = bind_workspace(executor, p, workspace, (hipStream_t)stream, true);
+    const ZeroPlace zp = place_zeroed_part(executor, workspace, (hipStream_t)stream);
+    hipError_t err = bind_workspace(executor, p, zp.base, workspace, (hipStream_t)stream, zp.zero);
     if (err == hipSuccess && !executor->act_seq.empty()) {
         // Per-batch lengths travel to the workspace as kernel arguments: copied when the launch is enqueued (or
         // captured into a graph), so no host memory has to outlive this call.
@@ -1112,6 +1199,7 @@ aclnnStatus aclnnSparsePagedAttention(void* workspace, uint64_t workspaceSize, a
         p.act_seq = lengths;
     }
     if (err == hipSuccess) err = spfa::launch_attention(p, (hipStream_t)stream);
+    launch_outcome(executor, zp, (hipStream_t)stream, err);
     return finish(executor, err, "sparse_paged_attention launch");
 }
 
@@ -1207,10 +1295,10 @@ aclnnStatus aclnnSparsePagedFusionAttention(void* workspace, uint64_t workspaceS
         const aclnnStatus ds = check_device(executor);
         if (ds != ACLNN_SUCCESS) { if (!executor->repeatable) delete executor; return ds; }
     }
-    const bool known_clean = executor->repeatable && executor->persistent_ws && executor->clean_ws == workspace;
-    hipError_t err = bind_workspace(executor, p, workspace, (hipStream_t)stream, !known_clean);
+    const ZeroPlace zp = place_zeroed_part(executor, workspace, (hipStream_t)stream);
+    hipError_t err = bind_workspace(executor, p, zp.base, workspace, (hipStream_t)stream, zp.zero);
     if (err == hipSuccess) err = spfa::launch_attention(p, (hipStream_t)stream);
-    if (executor->repeatable) executor->clean_ws = err == hipSuccess ? workspace : nullptr;
+    launch_outcome(executor, zp, (hipStream_t)stream, err);
     return finish(executor, err, "sparse_paged_fusion_attention launch");
 }
 
@@ -1311,20 +1399,26 @@ aclnnStatus aclnnAssignBlockIds(void*, uint64_t, aclOpExecutor* executor, aclrtS
 
 // Phase 2 of SparsePagedFusionAttention for callers that cannot allocate device memory: the workspace is a fixed array
 // inside the library's code object (one per GPU, 32 MiB) instead of a caller buffer.  Nothing is allocated or freed, on
-// the device or through any allocating runtime call.  The array keeps what the previous call left: the kernels leave
-// its counter area zeroed, and a zeroing kernel runs first whenever this launch needs a longer zeroed prefix than the
-// last one left (or the last enqueue failed).  Calls that overlap on one GPU share the array and race.
+// the device or through any allocating runtime call.  The array has a fixed part for what launches expect zeroed (its
+// first MiB) and a fixed part for data (from 2 MiB on): every launch leaves its own zeroed part zeroed and writes data
+// only behind 2 MiB, so between launches the first MiB holds zeros whatever ran before — launches of other executors with
+// larger or smaller plans, replays of captured launches — and no host-side record of earlier launches is consulted.  The
+// first MiB is zeroed once per device by the first call that is not being captured (a captured call made before that
+// records the zeroing of its own part into the graph).  Calls that overlap on one GPU share the array and race.
 aclnnStatus aclnnSparsePagedFusionAttentionNoAlloc(aclOpExecutor* executor, const aclrtStream stream) {
     REQUIRE_PTR(executor, "executor");
     REQUIRE(executor->op == kOpFusion, "executor was not created by aclnnSparsePagedFusionAttentionGetWorkspaceSize");
     auto drop = [&]() { if (!executor->repeatable) delete executor; };
-    if (executor->ws_bytes > spfa::kStaticScratchBytes) {
+    const uint64_t data_bytes = executor->ws_bytes - executor->ws_zero_bytes;
+    if (executor->ws_zero_bytes > spfa::kScratchZeroBytes || data_bytes > spfa::kStaticScratchBytes - spfa::kScratchDataOff) {
         const unsigned long long need = executor->ws_bytes;
         drop();
         return fail(ACLNN_ERR_PARAM_INVALID,
-                    "this launch needs %llu bytes of workspace, the built-in scratch holds %llu: plan it with "
-                    "spfaSetTailSharing(0) (and spfaSetMaxSplit(1) for small batches), or pass a workspace to "
-                    "aclnnSparsePagedFusionAttention", need, (unsigned long long)spfa::kStaticScratchBytes);
+                    "this launch needs %llu bytes of workspace, the built-in scratch holds %llu (%llu of them for counters): "
+                    "plan it with spfaSetTailSharing(0) (and spfaSetMaxSplit(1) for small batches), or pass a workspace to "
+                    "aclnnSparsePagedFusionAttention", need,
+                    (unsigned long long)(spfa::kStaticScratchBytes - spfa::kScratchDataOff + spfa::kScratchZeroBytes),
+                    (unsigned long long)spfa::kScratchZeroBytes);
     }
     {
         const aclnnStatus ds = check_device(executor);
@@ -1334,13 +1428,17 @@ aclnnStatus aclnnSparsePagedFusionAttentionNoAlloc(aclOpExecutor* executor, cons
     int dev = -1;
     hipError_t err = spfa::static_scratch(&scratch_ptr, &dev);
     if (err != hipSuccess) { drop(); return hip_fail(err, "address of the built-in scratch"); }
-    // zeroed prefix the previous launch on this device left (its own counter area), per device
-    static uint64_t zero_prefix[64];
+    if (dev < 0 || dev >= spfa::kMaxScratchDevices) { drop(); return fail(ACLNN_ERR_RUNTIME_ERROR, "device %d out of range", dev); }
     spfa::AttnParams p = executor->attn;
-    const uint64_t had = __atomic_load_n(&zero_prefix[dev], __ATOMIC_ACQUIRE);
-    err = bind_workspace(executor, p, scratch_ptr, (hipStream_t)stream, executor->ws_zero_bytes > had);
+    const bool capturing = stream_is_capturing((hipStream_t)stream);
+    const bool first = !__atomic_load_n(&g_noalloc_zeroed[dev], __ATOMIC_ACQUIRE);
+    if (first && !capturing)   // once per device: the whole fixed zeroed part
+        err = spfa::launch_zero(scratch_ptr, spfa::kScratchZeroBytes, nullptr, 0, (hipStream_t)stream);
+    // the data offsets of the plan count from the start of a workspace whose first ws_zero_bytes hold the zeroed part
+    char* const data_base = (char*)scratch_ptr + spfa::kScratchDataOff - executor->ws_zero_bytes;
+    if (err == hipSuccess) err = bind_workspace(executor, p, scratch_ptr, data_base, (hipStream_t)stream, first && capturing);
     if (err == hipSuccess) err = spfa::launch_attention(p, (hipStream_t)stream);
-    __atomic_store_n(&zero_prefix[dev], err == hipSuccess ? executor->ws_zero_bytes : 0, __ATOMIC_RELEASE);
+    if (!capturing) __atomic_store_n(&g_noalloc_zeroed[dev], err == hipSuccess, __ATOMIC_RELEASE);
     return finish(executor, err, "sparse_paged_fusion_attention launch (built-in scratch)");
 }
 

@@ -60,11 +60,16 @@ __global__ void zero_kernel(unsigned long long* a, size_t na, unsigned long long
     for (size_t j = i; j < nb; j += step) b[j] = 0ull;
 }
 
+static unsigned long long g_launches = 0;
+void count_launch() { __atomic_fetch_add(&g_launches, 1ull, __ATOMIC_RELAXED); }
+unsigned long long launches_so_far() { return __atomic_load_n(&g_launches, __ATOMIC_RELAXED); }
+
 hipError_t launch_zero(void* a, size_t a_bytes, void* b, size_t b_bytes, hipStream_t s) {
     const size_t na = a ? a_bytes / 8 : 0, nb = b ? b_bytes / 8 : 0;
     if (na + nb == 0) return hipSuccess;
     const size_t most = na > nb ? na : nb;
     const unsigned blocks = (unsigned)((most + 255) / 256 < 64 ? (most + 255) / 256 : 64);
+    count_launch();
     hipLaunchKernelGGL(zero_kernel, dim3(blocks), dim3(256), 0, s, (unsigned long long*)a, na, (unsigned long long*)b, nb);
     return hipGetLastError();
 }
@@ -82,6 +87,7 @@ hipError_t launch_store_lengths(long long* dst, const long long* host, int n, hi
         const int m = n - base < kLengthsPerLaunch ? n - base : kLengthsPerLaunch;
         for (int i = 0; i < m; ++i) pack.v[i] = host[base + i];
         for (int i = m; i < kLengthsPerLaunch; ++i) pack.v[i] = 0;
+        count_launch();
         hipLaunchKernelGGL(store_lengths_kernel, dim3((m + 255) / 256), dim3(256), 0, s, dst + base, pack, m);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
@@ -166,6 +172,7 @@ static hipError_t launch_cent(const CentParams& p, int mode, hipStream_t s) {
     static int lds_limit[2][kMaxDevices];
     const hipError_t le = ensure_lds_limit(kern, lds_limit[mode], p.lds_bytes);
     if (le != hipSuccess) return le;
+    count_launch();
     if (mode == 0) hipLaunchKernelGGL(cent_kernel<0>, grid, dim3(kCentWaves * 64), p.lds_bytes, s, p);
     else hipLaunchKernelGGL(cent_kernel<1>, grid, dim3(kCentWaves * 64), p.lds_bytes, s, p);
     return hipGetLastError();
@@ -183,6 +190,7 @@ hipError_t launch_assign(const AssignParams& p, hipStream_t s) {
     static int lds_limit[kMaxDevices];
     const hipError_t le = ensure_lds_limit((const void*)assign_kernel, lds_limit, p.lds_bytes);
     if (le != hipSuccess) return le;
+    count_launch();
     hipLaunchKernelGGL(assign_kernel, dim3((unsigned)(groups * p.Hkv)), dim3(kThreads), p.lds_bytes, s, p);
     return hipGetLastError();
 }
@@ -191,6 +199,7 @@ hipError_t launch_select_position(const SelectParams& p, hipStream_t s) {
     const long long rows = (long long)p.B * p.Hq;
     if (rows == 0) return hipSuccess;
     const dim3 grid((unsigned)((rows + 3) / 4));
+    count_launch();
     hipLaunchKernelGGL(select_position_kernel, grid, dim3(kThreads), (size_t)4 * p.k * sizeof(int32_t), s, p);
     return hipGetLastError();
 }

@@ -205,7 +205,20 @@ hipError_t launch_store_lengths(long long* dst, const long long* host, int n, hi
 // Library-owned scratch of the current device (a file-scope __device__ array, zero when the library is loaded) for the
 // entry point that takes no workspace: its device address and size.  Looked up once per device.
 constexpr size_t kStaticScratchBytes = (size_t)32 << 20;
+// Its layout: [0, kScratchZeroBytes) the zeroed part (counters, arrival words, boards) of launches through the entry
+// point that takes no workspace; then kScratchSlots slots of kScratchSlotBytes, the zeroed parts of launches that bring
+// a workspace, one slot per (device, stream); from kScratchDataOff on the data areas of the launches without workspace.
+constexpr size_t kScratchZeroBytes = (size_t)1 << 20;
+constexpr size_t kScratchSlotsOff = kScratchZeroBytes;
+constexpr size_t kScratchSlotBytes = (size_t)64 << 10;
+constexpr int kScratchSlots = 16;
+constexpr size_t kScratchDataOff = kScratchSlotsOff + kScratchSlots * kScratchSlotBytes;
+constexpr int kMaxScratchDevices = 64;   // devices the per-device tables of the library are sized for
 hipError_t static_scratch(void** ptr, int* device);
+// Kernels this library has enqueued (or recorded into a graph) since it was loaded, all threads and devices: lets a
+// caller check "one kernel per call" without a profiler.
+void count_launch();
+unsigned long long launches_so_far();
 // Compute units of the current device (0 when no device can be queried).
 int device_cu_count();
 // Number of q heads of a group one pass over the K/V pages serves, and whether that pass runs on the MFMA streamer

@@ -65,6 +65,8 @@ spfaSetAntiquantMode = _sig("spfaSetAntiquantMode", c_int, [c_int64])
 spfaSetSoftmaxLseOut = _sig("spfaSetSoftmaxLseOut", c_int, [c_void_p, c_int64])
 spfaSetSharedPrefix = _sig("spfaSetSharedPrefix", c_int, [c_void_p, c_void_p, c_int64, c_int64])
 spfaSetWorkspacePersistent = _sig("spfaSetWorkspacePersistent", c_int, [T, c_int])
+spfaSetLibraryCounters = _sig("spfaSetLibraryCounters", c_int, [c_int])
+spfaKernelLaunches = _sig("spfaKernelLaunches", c_uint64, [])
 spfaVersion = _sig("spfaVersion", c_char_p, [])
 
 _WS = [POINTER(c_uint64), POINTER(T)]          # uint64_t* workspaceSize, aclOpExecutor** executor

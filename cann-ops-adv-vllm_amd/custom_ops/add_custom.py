@@ -52,6 +52,14 @@ def _set_knobs(k=None, sink_recent=False, max_pages_cap=False, page_size=128):
     _abi.check(_abi.spfaSetPageSize(int(page_size)), "spfaSetPageSize")
 
 
+def _clear_knobs():
+    """Back to the defaults: a call that failed before its phase 1 must not leave one-shot settings armed."""
+    _abi.spfaSetTopK(64)
+    _abi.spfaSetSinkRecent(0)
+    _abi.spfaSetPageCap(0)
+    _abi.spfaSetPageSize(128)
+
+
 def incre_flash_attention_v4(*args, **kwargs):
     """Stock dense IncreFlashAttention (add_custom.py:10-40): not part of the sparse paged path."""
     raise NotImplementedError("incre_flash_attention_v4 is outside the sparse paged attention path")
@@ -86,6 +94,7 @@ def select_position(block_ids: torch.Tensor, block_table: torch.Tensor, seq_len:
         _set_knobs(page_size=page_size)   # one-shot settings: right in front of the phase 1 that consumes them
         _abi.run(_abi.aclnnSelectPositionGetWorkspaceSize, _abi.aclnnSelectPosition, descs, dev, "aclnnSelectPosition")
     finally:
+        _clear_knobs()
         _destroy(descs)
     return pos, length, gather
 
@@ -109,6 +118,7 @@ def cent_select(query: torch.Tensor, l1_cent: torch.Tensor, block_ids: torch.Ten
         _set_knobs(k, sink_recent, max_pages_cap, page_size)
         _abi.run(_abi.aclnnCentSelectGetWorkspaceSize, _abi.aclnnCentSelect, descs, dev, "aclnnCentSelect")
     finally:
+        _clear_knobs()
         _destroy(descs)
     return pos, length, max_len
 
@@ -258,13 +268,15 @@ def sparse_paged_fusion_attention(query: torch.Tensor, key: torch.Tensor, value:
         int(num_heads), float(scale_value), str(input_layout).encode(), int(num_key_value_heads), int(block_size),
         int(inner_precise)] + outs
     try:
-        _set_knobs(k, sink_recent, max_pages_cap)
+        # one-shot settings, armed right in front of the phase 1 that consumes them (the checks that can raise first)
         _set_attention_extras(softmax_lse, key_shared_prefix, value_shared_prefix, actual_shared_prefix_len, key,
                               int(num_key_value_heads), int(block_size), antiquant_mode)
+        _set_knobs(k, sink_recent, max_pages_cap)
         _abi.run(_abi.aclnnSparsePagedFusionAttentionGetWorkspaceSize, _abi.aclnnSparsePagedFusionAttention, args,
                  dev, "aclnnSparsePagedFusionAttention")
     finally:
         _clear_attention_extras()
+        _clear_knobs()
         _destroy(tens + mid + rest + outs, [kl, vl])
     return out, block_position, max_page_position_length
 
@@ -278,7 +290,8 @@ def assign_block_ids(key: torch.Tensor, block_table: torch.Tensor, seq_len: torc
     Not in the reference, which only consumes block_ids (README.md:33): for every sequence b and logical page i
     with first_new_page[b] <= i < ceil(seq_len[b] / block_size) (at most max_new_pages per sequence; 0 = all) and every
     kv head, the mean K row of the page (rounded to l1_cent's dtype) is scored against the head's centroids like a
-    query row and the page gets the best cluster's id (ties: smallest id).  A decode loop calls this when a page
+    query row and the page gets the best cluster's id (ties: smallest id).  A page whose block_table entry lies outside
+    the KV pool (the usual -1 of an unassigned slot) is skipped.  A decode loop calls this when a page
     fills up and advances first_new_page itself."""
     _abi.require_gpu(key, block_table, seq_len, l1_cent, block_ids, first_new_page)
     dev = key.device
@@ -326,9 +339,11 @@ class PreparedFusion:
                                                                                 ctypes.byref(self._exec)),
                            "aclnnSparsePagedFusionAttentionGetWorkspaceSize")
         finally:
+            _clear_knobs()
             _destroy(tens + rest + outs, [kl, vl])
         _abi.check(_abi.aclSetAclOpExecutorRepeatable(self._exec), "aclSetAclOpExecutorRepeatable")
-        self._ws = torch.empty(max(int(ws_size.value), 1), dtype=torch.uint8, device=self.device)
+        # zeroed here, once: whatever the first launch is (eager, or recorded into a graph) it finds clean counters
+        self._ws = torch.zeros(max(int(ws_size.value), 1), dtype=torch.uint8, device=self.device)
         self._ws_size = int(ws_size.value)
         # the workspace belongs to this plan alone, so its counters stay as every launch leaves them (zeroed): after
         # the first launch each run() is exactly one kernel

@@ -5,7 +5,7 @@ sparse_paged_fusion_attention_split_Bbn2s2_Us2.h:4444-4446); the only cross-row 
 max_page_position_length.  So rank r simply owns a contiguous slice of the batch with its q rows,
 total_seq_len entries, block_table rows and the KV pages they reference; l1_cent is replicated.  No KV
 or activation crosses xGMI.  The one collective is a MAX all-reduce of a single int64 (the global
-max_page_position_length), issued on a side stream so it never sits between two decode launches.
+max_page_position_length), issued on side streams so it never sits between two decode launches.
 The reference itself has no multi-device code.
 """
 from __future__ import annotations
@@ -32,46 +32,81 @@ def shard_batch(rank: int, world: int, query: torch.Tensor, total_seq_len: torch
 
 
 class GlobalMaxLength:
-    """All-reduce(MAX) of max_page_position_length over the ranks, overlapped with the next launch.
+    """All-reduce(MAX) of max_page_position_length over the ranks, off the path of the decode launches.
 
-    submit(pmax) snapshots the rank-local maximum on a side stream and starts the 8-byte all-reduce
-    there (RCCL when the tensors are on a GPU, gloo on the CPU); before_launch() makes the compute
-    stream wait only for that snapshot, so the next launch may overwrite pmax while the collective
-    is still in flight.
+    submit(pmax) takes a snapshot of the rank-local maximum on a side stream and runs the 8-byte all-reduce (RCCL when
+    the tensors are on a GPU, gloo on the CPU) on a second side stream.  before_launch() makes the compute stream
+    wait for the most recent snapshot only, so the next launch may overwrite pmax while collectives are still in
+    flight.  Snapshots rotate through `depth` buffers: a snapshot waits for the collective that last used its buffer,
+    i.e. the one `depth` submissions back, so a collective may lag up to depth - 1 steps behind the launches before
+    anybody on the compute stream notices.  `every` = N submits on every N-th call only (0: never): a serving loop
+    that needs the global maximum once per several steps, or an A/B of what the collective costs.
+
+    collective_ms() is the mean duration of the timed all-reduces (events on the collective's stream).
     """
 
-    def __init__(self, device, group: Optional[dist.ProcessGroup] = None):
+    def __init__(self, device, group: Optional[dist.ProcessGroup] = None, every: int = 1, depth: int = 4):
         self.device = torch.device(device)
         self.group = group
+        self.every = int(every)
+        self.depth = max(1, int(depth))
         self.cuda = self.device.type == "cuda"
-        self.stream = torch.cuda.Stream(self.device) if self.cuda else None
-        self.buf = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.calls = 0
+        self.submitted = 0
+        self.bufs = [torch.zeros(1, dtype=torch.int64, device=self.device) for _ in range(self.depth)]
+        self.buf = self.bufs[0]                      # the buffer of the most recent submission
         self.snapshot_done = None
-        self.work = None
+        self.timed = []                              # (start, end) events of the all-reduces
+        if self.cuda:
+            self.snap_stream = torch.cuda.Stream(self.device)
+            self.coll_stream = torch.cuda.Stream(self.device)
+            self.coll_done = [None] * self.depth
 
     def before_launch(self):
         if self.cuda and self.snapshot_done is not None:
             torch.cuda.current_stream(self.device).wait_event(self.snapshot_done)
 
     def submit(self, max_page_position_length: torch.Tensor):
+        self.calls += 1
+        if self.every <= 0 or self.calls % self.every != 0:
+            return
+        slot = self.submitted % self.depth
+        self.submitted += 1
+        buf = self.bufs[slot]
+        self.buf = buf
         if not self.cuda:
-            self.buf.copy_(max_page_position_length[:, 0].max().reshape(1))
-            dist.all_reduce(self.buf, op=dist.ReduceOp.MAX, group=self.group)
+            buf.copy_(max_page_position_length[:, 0].max().reshape(1))
+            dist.all_reduce(buf, op=dist.ReduceOp.MAX, group=self.group)
             return
         produced = torch.cuda.current_stream(self.device).record_event()
-        with torch.cuda.stream(self.stream):
-            self.stream.wait_event(produced)
-            if self.work is not None:
-                self.work.wait()          # previous all-reduce still owns buf
-            self.buf.copy_(max_page_position_length[:, 0].max().reshape(1))
-            self.snapshot_done = self.stream.record_event()
-            self.work = dist.all_reduce(self.buf, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
+        with torch.cuda.stream(self.snap_stream):
+            self.snap_stream.wait_event(produced)
+            if self.coll_done[slot] is not None:     # the collective that last used this buffer
+                self.snap_stream.wait_event(self.coll_done[slot])
+            buf.copy_(max_page_position_length[:, 0].max().reshape(1))
+            self.snapshot_done = self.snap_stream.record_event()
+        with torch.cuda.stream(self.coll_stream):
+            self.coll_stream.wait_event(self.snapshot_done)
+            timed = len(self.timed) < 256
+            if timed:
+                start = torch.cuda.Event(enable_timing=True)
+                start.record(self.coll_stream)
+            dist.all_reduce(buf, op=dist.ReduceOp.MAX, group=self.group)
+            done = torch.cuda.Event(enable_timing=timed)
+            done.record(self.coll_stream)
+            self.coll_done[slot] = done
+            if timed:
+                self.timed.append((start, done))
 
     def wait(self) -> torch.Tensor:
+        """Block until every submitted collective is complete; returns the most recent global maximum."""
         if self.cuda:
-            with torch.cuda.stream(self.stream):
-                if self.work is not None:
-                    self.work.wait()
-                    self.work = None
-            self.stream.synchronize()
+            self.snap_stream.synchronize()
+            self.coll_stream.synchronize()
         return self.buf
+
+    def collective_ms(self) -> Optional[float]:
+        """Mean duration of the timed all-reduces in ms (None before any has run).  Call after wait()."""
+        if not self.cuda or not self.timed:
+            return None
+        return sum(a.elapsed_time(b) for a, b in self.timed) / len(self.timed)

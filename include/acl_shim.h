@@ -162,6 +162,17 @@ SPFA_API aclnnStatus spfaSetSharedPrefix(const void* keyPrefix, const void* valu
  * them: the zeroing kernel then runs only the first time a workspace pointer is seen, and every later call is exactly
  * one kernel launch.  Default 0 (the workspace is scratch that the caller may reuse between calls). */
 SPFA_API aclnnStatus spfaSetWorkspacePersistent(aclOpExecutor* executor, int enable);
+/* Where the counters of a launch of the two attention ops live (per thread, stays until changed; default 1).
+ * 1: when they fit 64 KiB (batches up to about 4,000 sequences) they are kept in a slot of device memory that the
+ * library owns — one slot per (device, stream), sixteen per device, zeroed once and left zeroed by every launch — so
+ * a call with any caller workspace enqueues exactly one kernel and only the data areas of the workspace are used.
+ * Launches on one stream are ordered, which is what makes sharing a slot safe.  Launches that are being captured into
+ * a graph (a replay may run on any stream), launches on the hipStreamPerThread handle and launches beyond the sixteen
+ * slots keep their counters in the caller's workspace behind the zeroing kernel, as with 0. */
+SPFA_API aclnnStatus spfaSetLibraryCounters(int enable);
+/* Kernels the library has enqueued (or recorded into a graph) since it was loaded, over all threads and devices: the
+ * difference around a call tells how many kernels that call was. */
+SPFA_API uint64_t spfaKernelLaunches(void);
 SPFA_API const char* spfaVersion(void);
 
 #ifdef __cplusplus

@@ -478,7 +478,9 @@ def page_means(key_cache, block_table, seq_len, first_new_page, num_kv_heads: in
         page_len = max(0, min((int(seq_len[b]) + block_size - 1) // block_size, max_page))
         f0 = max(0, int(first[b]))
         for page in range(f0, min(page_len, f0 + max_new)):
-            phys = int(np.clip(bt[b, page], 0, n_blocks - 1))
+            phys = int(bt[b, page])
+            if phys < 0 or phys >= n_blocks:     # an unassigned slot names no page: skipped
+                continue
             valid = min(block_size, int(seq_len[b]) - page * block_size)
             m = np.zeros((Hkv, D), np.float32)
             for n2 in range(Hkv):

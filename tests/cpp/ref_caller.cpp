@@ -230,8 +230,16 @@ int main(int argc, char** argv) {
         pagePositionLengthTensor, maxPagePositionLengthTensor, attentionOutTensor, &workspaceSize, &executor));
     ACL_OK(aclSetAclOpExecutorRepeatable(executor));
     void* workspaceAddr = nullptr;
-    if (workspaceSize > 0) HIP_OK(hipMalloc(&workspaceAddr, workspaceSize));
-    for (int i = 0; i < 2; ++i) ACL_OK(aclnnSparsePagedFusionAttention(workspaceAddr, workspaceSize, executor, stream));
+    if (workspaceSize > 0) {
+        HIP_OK(hipMalloc(&workspaceAddr, workspaceSize));
+        HIP_OK(hipMemset(workspaceAddr, 0xEE, workspaceSize));   // a workspace is scratch: nothing may rely on its contents
+    }
+    // the launch repeated on one executor and one workspace (:886-895); the library's own count tells how many kernels
+    // that was: one per launch, plus at most one that zeroes the stream's counters the first time
+    const int kLaunches = 5;
+    const uint64_t launched0 = spfaKernelLaunches();
+    for (int i = 0; i < kLaunches; ++i) ACL_OK(aclnnSparsePagedFusionAttention(workspaceAddr, workspaceSize, executor, stream));
+    const uint64_t launched = spfaKernelLaunches() - launched0;
 
     if (queryTensor) aclDestroyTensor(queryTensor);
     if (tensorKeyList) aclDestroyTensorList(tensorKeyList);
@@ -249,6 +257,7 @@ int main(int argc, char** argv) {
         (rc = download(dir, "pos.bin", block_position)) || (rc = download(dir, "plen.bin", page_position_length)) ||
         (rc = download(dir, "pmax.bin", max_page_position_length)))
         return rc;
-    printf("ok: workspace %llu bytes\n", (unsigned long long)workspaceSize);
+    printf("ok: workspace %llu bytes, %llu kernels for %d launches\n", (unsigned long long)workspaceSize,
+           (unsigned long long)launched, kLaunches);
     return 0;
 }

@@ -80,6 +80,24 @@ def test_assign_is_bit_exact_on_grid_pages(B, Hkv, D, C, bs, max_page, layout, d
     assert (got != c["ids0"]).any()                  # something was assigned; everything else kept its id (equality above)
 
 
+def test_table_entries_outside_the_pool_are_skipped():
+    """An unassigned slot (-1) or an entry beyond the pool inside the new range names no page: no cluster id is
+    written for it — in particular not over physical page 0 or the last page, where a clamp would send it."""
+    c = _case(77, 4, 2, 128, 256, 128, 10, "BSH", "f16")
+    page_len = (c["seq"] + 127) // 128
+    c["first"][:] = 0
+    n_blocks = c["k"].shape[0]
+    c["table"][0, 1] = -1
+    c["table"][0, int(page_len[0]) - 1] = n_blocks + 5
+    c["table"][2, 0] = -7
+    used = set(int(x) for b in range(4) for x in c["table"][b, :page_len[b]] if 0 <= x < n_blocks)
+    got = _run(c)
+    want, _ = ref.assign_block_ids(c["k"], c["table"], c["seq"], c["first"], c["l1"], c["ids0"], 128, "BSH", 0)
+    assert np.array_equal(got, want)
+    untouched = [p for p in range(n_blocks) if p not in used]
+    assert untouched and np.array_equal(got[:, untouched], c["ids0"][:, untouched])
+
+
 def test_max_new_pages_bounds_what_one_call_assigns():
     c = _case(91, 6, 2, 128, 256, 128, 16, "BSH", "f16")
     for max_new in (1, 3):

@@ -30,6 +30,8 @@ def ops():
                                            (512, 16, 4, 2, 512), (1024, 32, 4, 4, 512),    # the largest head dim
                                            (640, 640, 8, 8, 512),    # ... with k = C: 1 KiB rows beside the largest sort buffers
                                            (1024, 1000, 4, 2, 256),
+                                           (16384, 1024, 2, 1, 128),   # the documented upper limits together: one 64 KiB key row
+                                                                       # per pass beside an 8 KiB sort buffer
                                            (100, 7, 6, 2, 32)])   # D = 32 scores 256 centroids per step, C pads to 128
 def test_large_cluster_counts(H, ops, C, k, Hq, Hkv, D):
     B, bs, pages = 5, 128, 40

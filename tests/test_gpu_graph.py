@@ -96,3 +96,51 @@ def test_one_shot_launch_with_host_lengths_can_be_captured():
         graph.replay()
         torch.cuda.synchronize()
         assert float((out - want).abs().max()) <= 2e-6 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("Hq,Hkv,B", [(8, 2, 3), (32, 32, 40)])
+def test_first_launch_of_a_plan_may_be_a_captured_one(Hq, Hkv, B):
+    """A plan whose very first launch is recorded into a graph (nothing has run on its workspace yet), followed by an
+    eager launch BEFORE any replay, then replays: the eager launch must not take the recording for a launch that left
+    the workspace clean."""
+    import custom_ops
+    import gpu_helpers as H
+    D, C, topk, bs, max_page, kv_page_len = 128, 256, 8, 128, 40, 120
+    seq_lens = [int(x) for x in datagen.rng_for(2).integers(1, max_page * bs, size=B)]
+    q, l1 = datagen.cent_case(12, B, Hq, Hkv, D, C, grid=True)
+    ids, table, seq = datagen.page_case(12, Hkv, C, kv_page_len, B, max_page, seq_lens)
+    k, v = datagen.kv_case(12, kv_page_len, bs, Hkv, D, "BSH", dist="randn")
+    qd, kd, vd, l1d, td, idsd, seqd = (H.dev(x) for x in (q, k, v, l1, table, ids, seq))
+    outs = []
+    for captured_first in (False, True):
+        pos = torch.empty((B, Hq, 256), dtype=torch.int32, device=H.DEV)
+        plen = torch.empty((B, Hq, 8), dtype=torch.int32, device=H.DEV)
+        pmax = torch.empty((B, 8), dtype=torch.int64, device=H.DEV)
+        plan = custom_ops.PreparedFusion(qd, kd, vd, td, l1d, idsd, seqd, pos, plen, pmax, Hq, D ** -0.5, Hkv, bs, k=topk,
+                                         out_dtype=torch.float32)
+        plan._ws.fill_(0xAB)                             # as a workspace from an allocator would be
+        if captured_first:
+            side = torch.cuda.Stream()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(graph, stream=side):
+                    plan.run()
+            plan.run()                                   # eager, before any replay
+            torch.cuda.synchronize()
+            first = [t.clone() for t in (plan.out, pos, plen, pmax)]
+            graph.replay()
+            graph.replay()
+            torch.cuda.synchronize()
+            second = [t.clone() for t in (plan.out, pos, plen, pmax)]
+            for a, b in zip(first[1:], second[1:]):
+                assert torch.equal(a, b)
+            assert float((first[0] - second[0]).abs().max()) <= 2e-6 * float(first[0].abs().max())
+            outs.append(first)
+        else:
+            plan.run()
+            torch.cuda.synchronize()
+            outs.append([t.clone() for t in (plan.out, pos, plen, pmax)])
+        plan.close()
+    for a, b in zip(outs[0][1:], outs[1][1:]):
+        assert torch.equal(a, b)
+    assert float((outs[0][0] - outs[1][0]).abs().max()) <= 2e-6 * float(outs[0][0].abs().max())

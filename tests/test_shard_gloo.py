@@ -44,6 +44,14 @@ def _worker(rank, world, port, ret):
     else:
         red.submit(torch.zeros((1, 8), dtype=torch.int64))
     gmax = int(red.wait().item())
+    # every = 2: only every second call reaches the collective (and with it every rank, or none); every = 0: none does
+    sparse, never = shard.GlobalMaxLength("cpu", every=2), shard.GlobalMaxLength("cpu", every=0)
+    for step in range(5):
+        local = torch.full((1, 8), 100 * (step + 1) + rank, dtype=torch.int64)
+        sparse.submit(local)
+        never.submit(local)
+    assert sparse.submitted == 2 and int(sparse.wait().item()) == 100 * 4 + world - 1
+    assert never.submitted == 0 and int(never.wait().item()) == 0 and never.collective_ms() is None
     ret[rank] = (shard.shard_range(B, rank, world), pos, int(gmax))
     dist.barrier()
     dist.destroy_process_group()

@@ -80,12 +80,17 @@ def test_no_alloc_entry_point_equals_the_workspace_entry_point(tail):
         _abi.spfaSetTailSharing(1)
     keep = [a.run_with_workspace() for a, _ in plans]
     torch.cuda.synchronize()
+    # "allocates nothing", seen from the driver: the device's free memory (hipMemGetInfo) before and after the calls,
+    # which also counts what a library would allocate behind torch's back; torch's own allocator count beside it
     allocated = torch.cuda.memory_stats()["allocation.all.allocated"]
+    free_before, _ = torch.cuda.mem_get_info()
     for _ in range(2):                               # big then small, twice, back to back on one stream
         for _, b in plans:
             b.run_no_alloc()
-    assert torch.cuda.memory_stats()["allocation.all.allocated"] == allocated
     torch.cuda.synchronize()
+    free_after, _ = torch.cuda.mem_get_info()
+    assert torch.cuda.memory_stats()["allocation.all.allocated"] == allocated
+    assert free_after >= free_before
     for a, b in plans:
         want, got = a.results(), b.results()
         for w, g in zip(want[:3], got[:3]):
@@ -133,3 +138,59 @@ def test_no_alloc_entry_point_rejects_a_plan_beyond_its_scratch():
     with pytest.raises(_abi.AclError, match="built-in scratch holds"):
         plan.run_no_alloc()
     plan.close()
+
+
+def test_captured_no_alloc_launch_replays_after_other_launches():
+    """The scratch is shared by every launch on the GPU, so a captured launch must not depend on what the host believed
+    about the scratch when it was recorded: warm-up of A, capture of A, an eager launch of a smaller plan B (other
+    counters, other data areas), replay of A, eager B again, replay of A — every result equals the workspace entry
+    point's.  The calls inside the capture allocate nothing by construction (allocation is illegal there)."""
+    from custom_ops import _abi
+    big = make_case(41, 40, 32, 32, 40, 160)          # shared last items: boards + data areas in the scratch
+    small = make_case(42, 3, 8, 2, 24, 96)            # page-list split: arrival counters + partial states
+    mid = make_case(43, 24, 16, 16, 30, 120)          # a plan of its own size in between
+    _abi.check(_abi.spfaSetTailSharing(2), "spfaSetTailSharing")
+    try:
+        ref_a, a = Plan(big, 8), Plan(big, 8)
+        ref_b, b = Plan(small, 16), Plan(small, 16)
+        ref_c, c = Plan(mid, 8), Plan(mid, 8)
+    finally:
+        _abi.spfaSetTailSharing(1)
+    keep = [pl.run_with_workspace() for pl in (ref_a, ref_b, ref_c)]
+    torch.cuda.synchronize()
+    want = {id(pl): pl.results() for pl in (ref_a, ref_b, ref_c)}
+
+    def check(pl, ref_pl):
+        torch.cuda.synchronize()
+        got, exp = pl.results(), want[id(ref_pl)]
+        for w, g in zip(exp[:3], got[:3]):
+            assert torch.equal(w, g)
+        assert bool(torch.isfinite(got[3]).all())
+        assert float((exp[3] - got[3]).abs().max()) <= 2e-6 * float(exp[3].abs().max())
+        for t in (pl.pos, pl.plen, pl.pmax):
+            t.fill_(-7)
+        pl.out.fill_(float("nan"))
+
+    side = torch.cuda.Stream()
+    graph_a, graph_c = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        for pl in (a, c):
+            pl.stream = _abi.current_stream(pl.out.device)
+        # C is captured before it has ever run; A after an eager warm-up
+        with torch.cuda.graph(graph_c, stream=side):
+            c.run_no_alloc()
+        a.run_no_alloc()
+        side.synchronize()
+        with torch.cuda.graph(graph_a, stream=side):
+            a.run_no_alloc()
+    check(a, ref_a)
+    b.run_no_alloc(); check(b, ref_b)
+    graph_a.replay(); check(a, ref_a)
+    graph_c.replay(); check(c, ref_c)
+    b.run_no_alloc(); check(b, ref_b)
+    graph_a.replay(); check(a, ref_a)
+    graph_a.replay(); graph_c.replay(); check(a, ref_a); check(c, ref_c)
+    b.run_no_alloc(); check(b, ref_b)
+    del keep
+    for pl in (ref_a, a, ref_b, b, ref_c, c):
+        pl.close()

@@ -8,6 +8,6 @@ for i in $(seq $reps); do
   for pr in "${pairs[@]}"; do
     v=${pr%%|*}; f=${pr#*|}
     lib=$([ "$v" = main ] && echo cann-ops-adv-vllm_amd/lib || echo cann-ops-adv-vllm_amd/lib_var/$v)/libcust_opapi.so
-    SPFA_LIB=$lib timeout -k 10 200 python bench.py --steps 40 --warmup 5 --no-cpu-baseline $f "$@" 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('[$pr]', '%.4f' % d['roofline']['kernel_ms'])" || exit 1
+    SPFA_LIB=$lib timeout -k 10 200 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-dropin $f "$@" 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('[$pr]', '%.4f' % d['roofline']['kernel_ms'])" || exit 1
   done
 done

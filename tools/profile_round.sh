@@ -7,7 +7,7 @@ root=$(pwd)
 out=$root/gpurun_out/prof_$tag
 rm -rf $out; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-B="$root/bench.py --steps 10 --warmup 3 --no-cpu-baseline"
+B="$root/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-dropin"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_c3 -- python3 $B > $out/stats_c3.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_c5 -- python3 $B --kv-heads 8 --seqlen 131072 --topk 64 > $out/stats_c5.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_c4 -- python3 $B --kv int8 --seqlen 65536 > $out/stats_c4.log 2>&1

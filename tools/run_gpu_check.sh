@@ -5,7 +5,7 @@ timeout -k 10 600 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout
 tail -2 gpurun_out/t.log
 run() {
   echo "### $*"
-  timeout -k 10 200 python bench.py --steps 30 --warmup 5 --no-cpu-baseline "$@" 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('ms/step %.4f  tok/s %.0f  GB/s %.0f  frac %.3f  kernel_ms %.4f' % (d['ms_per_step'], d['value'], r['achieved'], r['frac'], r['kernel_ms']))"
+  timeout -k 10 200 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-dropin "$@" 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('ms/step %.4f  tok/s %.0f  GB/s %.0f  frac %.3f  kernel_ms %.4f' % (d['ms_per_step'], d['value'], r['achieved'], r['frac'], r['kernel_ms']))"
 }
 run
 run
