@@ -69,8 +69,9 @@ def parse(argv=None):
     ap.add_argument("--no-tail-sharing", action="store_true", help="diagnostic: spfaSetTailSharing(0)")
     ap.add_argument("--force-tail-sharing", action="store_true", help="diagnostic: spfaSetTailSharing(2)")
     ap.add_argument("--no-shared-scoring", action="store_true", help="diagnostic: spfaSetSharedScoring(0)")
-    ap.add_argument("--allreduce-every", type=int, default=1,
-                    help="multi-GPU: all-reduce the global max_page_position_length every N-th step (0: never)")
+    ap.add_argument("--allreduce-every", type=int, default=0,
+                    help="multi-GPU: all-reduce the global max_page_position_length every N-th step; 0 (default): once, "
+                         "after the last timed step (the final max_page_position_length), inside the timed region")
     ap.add_argument("--no-dropin", action="store_true",
                     help="skip the extra leg that times the reference-shaped call (custom_ops.sparse_paged_fusion_attention: "
                          "new descriptors, phase 1 and a new workspace on every call) beside the prepared launch")
@@ -78,9 +79,9 @@ def parse(argv=None):
                     help="preset shape: c3 = BASELINE configs[2] (the default shape), c4 = configs[3] (int8 KV, S=64k), "
                          "c5 = configs[4] (GQA 32/8, S=128k, k=64; 64 sequences per GPU, 512 in all on 8 GPUs)")
     a = ap.parse_args(argv)
-    if a.workload:
-        for key, val in WORKLOADS[a.workload].items():
-            setattr(a, key, val)
+    if a.workload:   # the preset supplies the defaults; options given beside it (--batch 8) still count
+        ap.set_defaults(**WORKLOADS[a.workload])
+        a = ap.parse_args(argv)
     return a
 
 
@@ -378,15 +379,37 @@ def main():
     if os.environ.get("BENCH_SINGLE_DEVICE") == "1":
         local_rank = 0
     backend = "none"
-    if world > 1:
+    # BENCH_FORCE_DIST=1 (rehearsal aid): a one-rank process group, so that RCCL and the side-stream collective run on a
+    # box with a single GPU too
+    force_dist = world == 1 and os.environ.get("BENCH_FORCE_DIST") == "1"
+    if force_dist:
+        import socket
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_PORT", str(sock.getsockname()[1]))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
+        # RCCL prints a version banner on STDOUT when its communicator comes up; stdout carries exactly one JSON line,
+        # so file descriptor 1 points at stderr until the communicator exists
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+                dist.all_reduce(torch.zeros(1, device=torch.device("cuda", local_rank)))
+                torch.cuda.synchronize()
+            else:
+                dist.init_process_group(backend)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     import custom_ops
@@ -404,17 +427,31 @@ def main():
     pos = torch.empty((B, Hq, 256), dtype=torch.int32, device=device)
     plen = torch.empty((B, Hq, 8), dtype=torch.int32, device=device)
     pmax = torch.empty((B, 8), dtype=torch.int64, device=device)
-    plan = custom_ops.PreparedFusion(wl["q"], wl["key"], wl["val"], wl["table"], wl["l1"], wl["block_ids"], wl["seq"],
-                                     pos, plen, pmax, Hq, D ** -0.5, Hkv, bs, antiquant_scale=wl["a_scale"],
-                                     antiquant_offset=wl["a_off"], k=a.topk)
-    reducer = shard.GlobalMaxLength(device, every=a.allreduce_every) if world > 1 else None
+    def make_plan(pos_, plen_, pmax_):
+        return custom_ops.PreparedFusion(wl["q"], wl["key"], wl["val"], wl["table"], wl["l1"], wl["block_ids"], wl["seq"],
+                                         pos_, plen_, pmax_, Hq, D ** -0.5, Hkv, bs, antiquant_scale=wl["a_scale"],
+                                         antiquant_offset=wl["a_off"], k=a.topk)
+
+    plan = make_plan(pos, plen, pmax)
+    reducer = shard.GlobalMaxLength(device, every=a.allreduce_every,
+                                    depth=int(os.environ.get("BENCH_REDUCER_DEPTH", "4"))) if dist is not None else None
+    # With a collective behind every launch the decode loop alternates two sets of output tensors (as a serving loop
+    # that hands step i's outputs on while step i + 1 runs would): a launch then never waits for the snapshot of the
+    # launch just before it.  BENCH_SINGLE_OUTPUTS=1 keeps one set (the A/B of that choice).
+    plans = [(plan, pmax)]
+    if reducer is not None and os.environ.get("BENCH_SINGLE_OUTPUTS") != "1":
+        pos2, plen2, pmax2 = torch.empty_like(pos), torch.empty_like(plen), torch.empty_like(pmax)
+        plans.append((make_plan(pos2, plen2, pmax2), pmax2))
+    step_no = [0]
 
     def step():
+        pl, pm = plans[step_no[0] % len(plans)]
+        step_no[0] += 1
         if reducer is not None:
-            reducer.before_launch()
-        plan.run()
+            reducer.before_launch(pm)
+        pl.run()
         if reducer is not None:      # the only collective of the path: global max_page_position_length
-            reducer.submit(pmax)
+            reducer.submit(pm)
 
     for _ in range(a.warmup):
         step()
@@ -430,6 +467,11 @@ def main():
     for i in range(a.steps):
         step()
     ev1.record()
+    if reducer is not None and a.allreduce_every <= 0:
+        # the final max_page_position_length over all ranks: the one collective the sharded path needs
+        reducer.every = 1
+        reducer.submit(plans[(step_no[0] - 1) % len(plans)][1])
+        reducer.every = 0
     torch.cuda.synchronize()
     if reducer is not None:
         reducer.wait()
@@ -481,7 +523,9 @@ def main():
                   "ranks_seen": (dist.get_world_size() if dist is not None else 1),
                   "kernel_ms_per_rank": rank_kernel_ms,
                   "collective": ((f"all_reduce(MAX) of one int64 every {a.allreduce_every} step(s) on a side stream"
-                                  if a.allreduce_every > 0 else "none (--allreduce-every 0)") if world > 1 else "none")},
+                                  if a.allreduce_every > 0 else
+                                  "one all_reduce(MAX) of one int64 after the last timed step (the final "
+                                  "max_page_position_length), inside the timed region") if dist is not None else "none")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                      "kernel_ms": kernel_ms,
@@ -493,11 +537,11 @@ def main():
                                                  "two events around the timed region, is lower than this median)"},
                      "algorithmic_bytes_per_launch": gbytes, "scope": "one GPU (rank 0)"},
     }
-    if world > 1:
+    if reducer is not None:
         result["ranks"]["allreduce_every"] = a.allreduce_every
         result["ranks"]["collectives_submitted"] = reducer.submitted
         result["ranks"]["collective_ms"] = reducer.collective_ms()   # rank 0's, events on the collective's stream
-    if rank == 0 and world == 1 and not a.no_dropin:
+    if rank == 0 and world == 1 and not a.no_dropin and not force_dist:
         try:
             result["dropin"] = dropin_leg(a, wl, custom_ops, _abi, pos, plen, pmax, plan.out.clone())
             result["dropin"]["vs_prepared"] = result["dropin"]["ms_per_step"] / kernel_ms
@@ -508,9 +552,12 @@ def main():
             result["cpu_baseline"] = cpu_baseline(a, wl, custom_ops, {"out": plan.out, "pos": pos})
         except Exception as e:   # the GPU number stands on its own; say why the CPU leg is missing
             result["cpu_baseline"] = {"value": None, "error": repr(e)}
+    if reducer is not None:
+        result["ranks"]["output_sets"] = len(plans)
     if rank == 0:
         print(json.dumps(result), flush=True)
-    plan.close()
+    for pl, _ in plans:
+        pl.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -842,6 +842,11 @@ static aclnnStatus plan_lds(spfa::AttnParams& p) {
         nq = (nq + 1) / 2;
         need = carve_lds(p, (size_t)nq);
     }
+    // ... and as the last resort every q head as a pass of its own (one key row: 64 KiB at the largest cluster count)
+    if (need > kMaxLds && nq > 1) {
+        nq = 1;
+        need = carve_lds(p, 1);
+    }
     p.rows_per_pass = nq;
     p.lds_bytes = need;
     p.pre_items = 0;

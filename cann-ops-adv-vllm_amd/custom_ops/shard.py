@@ -34,15 +34,20 @@ def shard_batch(rank: int, world: int, query: torch.Tensor, total_seq_len: torch
 class GlobalMaxLength:
     """All-reduce(MAX) of max_page_position_length over the ranks, off the path of the decode launches.
 
-    submit(pmax) takes a snapshot of the rank-local maximum on a side stream and runs the 8-byte all-reduce (RCCL when
-    the tensors are on a GPU, gloo on the CPU) on a second side stream.  before_launch() makes the compute stream
-    wait for the most recent snapshot only, so the next launch may overwrite pmax while collectives are still in
-    flight.  Snapshots rotate through `depth` buffers: a snapshot waits for the collective that last used its buffer,
-    i.e. the one `depth` submissions back, so a collective may lag up to depth - 1 steps behind the launches before
-    anybody on the compute stream notices.  `every` = N submits on every N-th call only (0: never): a serving loop
-    that needs the global maximum once per several steps, or an A/B of what the collective costs.
+    With RCCL: submit(pmax) takes a snapshot of the rank-local maximum on a side stream (one small kernel) and runs the
+    8-byte all-reduce on a second side stream; nothing on the host ever waits.  The only thing the compute stream has to
+    respect is that a launch must not overwrite a pmax tensor whose snapshot is still to be taken:
+    before_launch(pmax) makes it wait for the last snapshot that read THAT tensor.  A decode loop that alternates two
+    sets of output tensors therefore never waits for the snapshot of the step just launched — that wait, on a single
+    set of outputs, is a bubble of two dependent tiny kernels between every two launches (measured: 35 us per step).
+    Snapshots rotate through `depth` buffers: a snapshot waits for the collective that last used its buffer, the one
+    `depth` submissions back.  `every` = N submits on every N-th call only (0: never): a serving loop that needs the
+    global maximum once per several steps, or an A/B of what the collective costs.
 
-    collective_ms() is the mean duration of the timed all-reduces (events on the collective's stream).
+    With a backend that moves GPU tensors through the host (gloo: rehearsals of the ranks on one device) the value is
+    fetched to the host (which waits for the launch) and reduced there: correct, not overlapped.
+
+    collective_ms() is the mean duration of the timed all-reduces (events on the collective's stream; RCCL only).
     """
 
     def __init__(self, device, group: Optional[dist.ProcessGroup] = None, every: int = 1, depth: int = 4):
@@ -55,16 +60,26 @@ class GlobalMaxLength:
         self.submitted = 0
         self.bufs = [torch.zeros(1, dtype=torch.int64, device=self.device) for _ in range(self.depth)]
         self.buf = self.bufs[0]                      # the buffer of the most recent submission
-        self.snapshot_done = None
+        self.snapshots = {}                          # data_ptr of a pmax tensor -> event of the last snapshot that read it
         self.timed = []                              # (start, end) events of the all-reduces
-        if self.cuda:
+        self.stream_ordered = self.cuda and dist.get_backend(group) == "nccl"
+        if self.stream_ordered:
             self.snap_stream = torch.cuda.Stream(self.device)
             self.coll_stream = torch.cuda.Stream(self.device)
             self.coll_done = [None] * self.depth
 
-    def before_launch(self):
-        if self.cuda and self.snapshot_done is not None:
-            torch.cuda.current_stream(self.device).wait_event(self.snapshot_done)
+    def before_launch(self, max_page_position_length: Optional[torch.Tensor] = None):
+        """Call before a launch that writes `max_page_position_length` (None: any tensor ever submitted)."""
+        if not self.stream_ordered:
+            return
+        cur = torch.cuda.current_stream(self.device)
+        if max_page_position_length is None:
+            for ev in self.snapshots.values():
+                cur.wait_event(ev)
+        else:
+            ev = self.snapshots.get(max_page_position_length.data_ptr())
+            if ev is not None:
+                cur.wait_event(ev)
 
     def submit(self, max_page_position_length: torch.Tensor):
         self.calls += 1
@@ -74,19 +89,28 @@ class GlobalMaxLength:
         self.submitted += 1
         buf = self.bufs[slot]
         self.buf = buf
-        if not self.cuda:
-            buf.copy_(max_page_position_length[:, 0].max().reshape(1))
-            dist.all_reduce(buf, op=dist.ReduceOp.MAX, group=self.group)
+        if not self.stream_ordered:
+            local = max_page_position_length[:, 0].max().reshape(1)
+            if self.cuda:                            # through the host: waits for the launch that produced the value
+                host = local.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.MAX, group=self.group)
+                buf.copy_(host)
+            else:
+                buf.copy_(local)
+                dist.all_reduce(buf, op=dist.ReduceOp.MAX, group=self.group)
             return
         produced = torch.cuda.current_stream(self.device).record_event()
         with torch.cuda.stream(self.snap_stream):
             self.snap_stream.wait_event(produced)
             if self.coll_done[slot] is not None:     # the collective that last used this buffer
                 self.snap_stream.wait_event(self.coll_done[slot])
-            buf.copy_(max_page_position_length[:, 0].max().reshape(1))
-            self.snapshot_done = self.snap_stream.record_event()
+            torch.amax(max_page_position_length[:, 0], dim=0, keepdim=True, out=buf)   # one kernel, straight into buf
+            snapshot_done = self.snap_stream.record_event()
+            self.snapshots[max_page_position_length.data_ptr()] = snapshot_done
         with torch.cuda.stream(self.coll_stream):
-            self.coll_stream.wait_event(self.snapshot_done)
+            # RCCL: the call only enqueues (the collective runs in stream order behind the snapshot), so it can be
+            # bracketed with events and nothing on the host ever waits for it
+            self.coll_stream.wait_event(snapshot_done)
             timed = len(self.timed) < 256
             if timed:
                 start = torch.cuda.Event(enable_timing=True)
@@ -100,13 +124,13 @@ class GlobalMaxLength:
 
     def wait(self) -> torch.Tensor:
         """Block until every submitted collective is complete; returns the most recent global maximum."""
-        if self.cuda:
+        if self.stream_ordered:
             self.snap_stream.synchronize()
             self.coll_stream.synchronize()
         return self.buf
 
     def collective_ms(self) -> Optional[float]:
         """Mean duration of the timed all-reduces in ms (None before any has run).  Call after wait()."""
-        if not self.cuda or not self.timed:
+        if not self.timed:
             return None
         return sum(a.elapsed_time(b) for a, b in self.timed) / len(self.timed)

@@ -93,5 +93,5 @@ def test_the_parent_starts_the_ranks_without_touching_torch_cuda(monkeypatch, tm
 
 def test_allreduce_every_is_an_option():
     import bench
-    assert bench.parse([]).allreduce_every == 1
-    assert bench.parse(["--allreduce-every", "0"]).allreduce_every == 0
+    assert bench.parse([]).allreduce_every == 0          # one collective, after the last step
+    assert bench.parse(["--allreduce-every", "1"]).allreduce_every == 1
