@@ -415,6 +415,10 @@ def main():
     import custom_ops
     from custom_ops import _abi, shard
 
+    if os.environ.get("SPFA_GEOM"):      # experiments: force the workgroup geometry of the one-q-head kernels (1 wide, 2 narrow)
+        _abi.spfaSetWorkgroupGeometry(int(os.environ["SPFA_GEOM"]))
+    if os.environ.get("SPFA_BATCHED_SELECTION"):
+        _abi.spfaSetBatchedSelection(int(os.environ["SPFA_BATCHED_SELECTION"]))
     if a.no_tail_sharing:
         _abi.spfaSetTailSharing(0)
     if a.force_tail_sharing:

@@ -8,6 +8,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 #include <cstring>
 #include <mutex>
@@ -64,6 +65,7 @@ thread_local int g_max_split = 16;
 thread_local int g_tail_sharing = 1;
 thread_local int g_shared_scoring = 1;
 thread_local int g_stream_slots = 1;       // 1: launches may keep their counters in library-owned per-stream slots
+thread_local int g_super_items = 1;        // 1: the planner may batch the selection of queue-fed launches (super-items)
 thread_local int g_geometry = 0;           // 0: planner's choice, 1: wide, 2: narrow workgroups of the one-q-head kernels
 thread_local int64_t g_page_size = 128;   // PAGESIZE of cent_select.cpp:17 / select_position.cpp:112
 thread_local const long long* g_act_seq_dev = nullptr;   // one-shot, consumed by the next attention plan
@@ -77,6 +79,7 @@ thread_local int g_antiq_mode = 0;          // one-shot: 0 per channel / per ten
 thread_local void* g_debug_buf = nullptr;   // diagnostic stamp buffer (see spfaSetDebugBuffer)
 
 constexpr size_t kMaxLds = 160 * 1024;    // LDS per CU on gfx950
+
 
 // The selection knobs (top-k, sink/recent pages, page cap, page size) are one-shot: the next phase 1 of an op that
 // reads them takes them and restores the defaults, whether that call succeeds or not, so a value set for one call can
@@ -330,6 +333,7 @@ aclnnStatus spfaSetWorkgroupGeometry(int geometry) {
     g_geometry = geometry;
     return ACLNN_SUCCESS;
 }
+aclnnStatus spfaSetBatchedSelection(int enable) { g_super_items = enable ? 1 : 0; return ACLNN_SUCCESS; }
 aclnnStatus spfaSetLibraryCounters(int enable) { g_stream_slots = enable ? 1 : 0; return ACLNN_SUCCESS; }
 aclnnStatus spfaSetPageSize(int64_t page_size) {
     if (page_size < 1 || page_size > 512) return fail(ACLNN_ERR_PARAM_INVALID, "page size %lld out of [1, 512]", (long long)page_size);
@@ -371,6 +375,20 @@ aclnnStatus spfaSetWorkspacePersistent(aclOpExecutor* e, int enable) {
 }
 // Diagnostic only: device buffer of >= grid*16*16 uint64 that -DSPFA_STAMPS builds fill with cycle stamps.
 __attribute__((visibility("default"))) aclnnStatus spfaSetDebugBuffer(void* dev) { g_debug_buf = dev; return ACLNN_SUCCESS; }
+// The launch plan of an executor of the two attention ops as text (for logs and tests): which kernel form and geometry,
+// how the work is dealt.  Returns the length written (without the terminator), or -1.
+int spfaDescribeExecutor(const aclOpExecutor* e, char* buf, uint64_t n) {
+    if (!e || !buf || n == 0 || (e->op != kOpAttention && e->op != kOpFusion)) return -1;
+    const spfa::AttnParams& p = e->attn;
+    const bool mfma = spfa::attention_uses_mfma(p.rows_per_pass, p.kv_dtype, p.D);
+    const int w = snprintf(buf, n,
+                           "form=%s geometry=%s rows_per_pass=%d scored_ahead=%d lists_ahead=%d super_items=%d split=%d "
+                           "tail_sharing=%d resident_workgroups=%lld lds_bytes=%zu workspace_bytes=%llu zeroed_bytes=%llu",
+                           mfma ? "mfma" : "valu", p.narrow ? "narrow" : "wide", p.rows_per_pass, p.pre_items, p.pre_lists,
+                           p.sup_items, p.n_split, p.tail_on, p.grid_cap, p.lds_bytes, (unsigned long long)e->ws_bytes,
+                           (unsigned long long)e->ws_zero_bytes);
+    return w < 0 ? -1 : (w < (int)n ? w : (int)n - 1);
+}
 uint64_t spfaKernelLaunches(void) { return spfa::launches_so_far(); }
 const char* spfaVersion(void) { return "spfa-hip-gfx950 0.1"; }
 
@@ -803,7 +821,10 @@ constexpr uint64_t kCounterBytes = 256;   // 8 work counters at the start of the
 static size_t carve_lds(spfa::AttnParams& p, size_t nq) {
     auto align16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
     size_t off = 0;
-    const size_t sel_rows = nq * (size_t)(p.pre_items > 1 ? p.pre_items : 1);   // rows whose selection is held at once
+    // rows whose score keys are held at once; rows whose page bitmaps are (super-items: the one being streamed and the
+    // one being prepared)
+    const size_t sel_rows = p.sup_items > 1 ? (size_t)p.sup_items : nq * (size_t)(p.pre_items > 1 ? p.pre_items : 1);
+    const size_t bit_rows = p.sup_items > 1 ? 2 * (size_t)p.sup_items : sel_rows;
     p.off_keys = (int)off;
     if (p.mode == 1) off += align16(sel_rows * p.Cp * 4);                  // score keys (selector wave)
     p.off_cbits = (int)off;
@@ -811,7 +832,7 @@ static size_t carve_lds(spfa::AttnParams& p, size_t nq) {
     if (p.mode == 1)   // top-k cluster bitmaps (one per wave that selects a row of the first item) + 16 row lengths
         off += align16((sel_rows < max_waves ? sel_rows : max_waves) * (size_t)(p.Cp / 32) * 4) + 64;
     p.off_pbits = (int)off;
-    if (p.mode == 1) off += align16(sel_rows * ((p.max_page + 63) / 64) * 8);   // per-head page bitmaps
+    if (p.mode == 1) off += align16(bit_rows * ((p.max_page + 63) / 64) * 8);   // per-head page bitmaps
     p.off_list = (int)off;
     off += align16((size_t)2 * p.max_entries * 8);                         // double-buffered page lists
     p.off_comb = (int)off;
@@ -919,6 +940,47 @@ static void plan_workspace(aclOpExecutor* e) {
         return false;
     };
     const bool ahead = try_scored_ahead();
+    // Batched selection through the queue (one q head per pass, more items than resident workgroups, no exact fit for the
+    // static form above): super-items of J consecutive sequences of one kv head, in phases of decreasing J.  A phase
+    // holds whole rounds of the grid (one super-item per resident workgroup and round), so every workgroup gets the same
+    // number of large super-items first; what does not fill a round goes to the next smaller size, the rest is dealt
+    // sequence by sequence and evens the launch out (the last item of each workgroup is shared on top of that).
+    // Taken only when the larger selection areas leave the residency unchanged.
+    auto try_super_items = [&](spfa::AttnParams& q, long long cap_now) {
+        q.sup_items = 0;
+        if (!(g_shared_scoring && g_super_items && q.mode == 1 && q.n_split == 1 && cap_now > 0 && items > cap_now && one_head &&
+              q.pre_items <= 1 && !q.token_mode && !q.antiq_per_token && q.B > 1))
+            return false;
+        const char* forced = getenv("SPFA_SUPER_J");   // experiments only: the largest J
+        const long long per_round = std::max<long long>(1, cap_now / q.Hkv);   // super-items per kv head in one round
+        spfa::AttnParams trial = q;
+        int rem = q.B, nph = 0, jmax = 0;
+        for (int ph = 0; ph < 4; ++ph) trial.sup_j[ph] = 1, trial.sup_n[ph] = 0;
+        for (int J = forced ? atoi(forced) : 8; J >= 1 && rem > 0 && nph < 4; J >>= 1) {
+            const bool last = J == 1 || nph == 3;
+            const long long n = last ? (rem + J - 1) / J : (rem / (J * per_round)) * per_round;
+            if (n <= 0) continue;
+            trial.sup_j[nph] = J;
+            trial.sup_n[nph] = (int)n;
+            rem -= (int)std::min<long long>(rem, n * J);
+            jmax = std::max(jmax, J);
+            ++nph;
+        }
+        if (jmax < 2) return false;
+        trial.sup_items = jmax;
+        trial.pre_items = 0;
+        trial.pre_lists = 0;
+        trial.lds_bytes = carve_lds(trial, (size_t)q.rows_per_pass);
+        long long cap2 = 0;
+        trial.grid_cap = 0;
+        if (trial.lds_bytes <= kMaxLds && spfa::launch_attention(trial, nullptr, &cap2) == hipSuccess && cap2 == cap_now) {
+            trial.grid_cap = cap_now;
+            q = trial;
+            return true;
+        }
+        return false;
+    };
+    const bool supers_wide = !ahead && try_super_items(p, cap);
     // The plain one-q-head kernel exists in two geometries: one workgroup of eight streamer waves per CU (wide: one pass
     // over the centroids per CU at the start, eight items scored ahead) and two workgroups of four (narrow: twice the
     // selector waves).  Wide wins whenever the selector has little to do beside the stream — lists given, every
@@ -927,12 +989,15 @@ static void plan_workspace(aclOpExecutor* e) {
     // consume them.
     const bool both = p.rows_per_pass == 1 && !p.token_mode && !p.antiq_per_token &&
                       !spfa::attention_uses_mfma(p.rows_per_pass, p.kv_dtype, p.D);
-    const bool want_narrow = g_geometry == 2 || (g_geometry == 0 && p.mode == 1 && cap > 0 && items > cap && !ahead);
+    // (with batched selection one selector wave feeds eight streamers: wide)
+    const bool want_narrow = g_geometry == 2 ||
+                             (g_geometry == 0 && p.mode == 1 && cap > 0 && items > cap && !ahead && !supers_wide);
     if (both && want_narrow && n_cu > 0) {
         spfa::AttnParams trial = p;
         trial.narrow = 1;
         trial.pre_items = 0;
         trial.pre_lists = 0;
+        trial.sup_items = 0;
         trial.lds_bytes = carve_lds(trial, (size_t)p.rows_per_pass);
         long long cap2 = 0;
         trial.grid_cap = 0;
@@ -948,7 +1013,7 @@ static void plan_workspace(aclOpExecutor* e) {
                 if (ns > p.max_entries) ns = p.max_entries;
                 if (ns > 1) p.n_split = (int)ns;
             }
-            (void)try_scored_ahead();
+            if (!try_scored_ahead()) (void)try_super_items(p, cap);
         }
     }
     // Which class (item % 8 = kv head % 8 when Hkv is a multiple of 8) a workgroup's claims start with.  Staying with

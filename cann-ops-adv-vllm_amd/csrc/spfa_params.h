@@ -163,6 +163,14 @@ struct AttnParams {
     // with pre_items > 1 — 1: the page lists of all those items are built before the first is streamed as well (one wave
     // per row); 0: only the scores are taken ahead, top-k and page selection of items 2.. stay with the selector waves
     int pre_lists;
+    // > 1 (fused op, one q head per pass): the queue hands out super-items of up to sup_items consecutive sequences of
+    // one kv head; the selector wave scores their rows in ONE pass over the head's centroids while the super-item
+    // before is streamed (the first one: by all waves, before anything is streamed)
+    int sup_items;
+    // The super-items of a launch come in up to four phases of decreasing size: phase i holds sup_n[i] super-items of
+    // sup_j[i] sequences for every kv head, numbered head-minor (super-item % heads = kv head) and handed out in that
+    // order, so every workgroup gets large ones first and the small ones even the launch out at its end.
+    int sup_j[4], sup_n[4];
     // page-list split for small batches: n_split workgroups per item (1: off)
     int n_split;
     // sharing of every workgroup's last item (n_split == 1 only): boards and their data areas in the workspace

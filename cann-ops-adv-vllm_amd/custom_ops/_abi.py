@@ -65,7 +65,9 @@ spfaSetAntiquantMode = _sig("spfaSetAntiquantMode", c_int, [c_int64])
 spfaSetSoftmaxLseOut = _sig("spfaSetSoftmaxLseOut", c_int, [c_void_p, c_int64])
 spfaSetSharedPrefix = _sig("spfaSetSharedPrefix", c_int, [c_void_p, c_void_p, c_int64, c_int64])
 spfaSetWorkspacePersistent = _sig("spfaSetWorkspacePersistent", c_int, [T, c_int])
+spfaSetBatchedSelection = _sig("spfaSetBatchedSelection", c_int, [c_int])
 spfaSetLibraryCounters = _sig("spfaSetLibraryCounters", c_int, [c_int])
+spfaDescribeExecutor = _sig("spfaDescribeExecutor", c_int, [T, ctypes.c_char_p, c_uint64])
 spfaKernelLaunches = _sig("spfaKernelLaunches", c_uint64, [])
 spfaVersion = _sig("spfaVersion", c_char_p, [])
 
@@ -89,6 +91,18 @@ aclnnAssignBlockIdsGetWorkspaceSize = _sig("aclnnAssignBlockIdsGetWorkspaceSize"
                                            [T] * 7 + [c_int64, c_int64, T] + _WS)
 aclnnAssignBlockIds = _sig("aclnnAssignBlockIds", c_int, _EXEC)
 aclnnSparsePagedFusionAttentionNoAlloc = _sig("aclnnSparsePagedFusionAttentionNoAlloc", c_int, [T, c_void_p])
+
+
+def describe(executor) -> dict:
+    """The launch plan of an attention executor as a dict (spfaDescribeExecutor)."""
+    buf = ctypes.create_string_buffer(512)
+    if spfaDescribeExecutor(executor, buf, 512) < 0:
+        raise AclError("spfaDescribeExecutor: not an attention executor")
+    out = {}
+    for part in buf.value.decode().split():
+        key, _, val = part.partition("=")
+        out[key] = int(val) if val.lstrip("-").isdigit() else val
+    return out
 
 
 class AclError(RuntimeError):

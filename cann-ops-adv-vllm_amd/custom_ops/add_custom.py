@@ -350,6 +350,10 @@ class PreparedFusion:
         _abi.check(_abi.spfaSetWorkspacePersistent(self._exec, 1 if persistent_workspace else 0),
                    "spfaSetWorkspacePersistent")
 
+    def describe(self) -> dict:
+        """The launch plan (kernel form, geometry, how the work is dealt): see spfaDescribeExecutor."""
+        return _abi.describe(self._exec)
+
     def run(self) -> torch.Tensor:
         """Enqueue one fused launch on torch's current stream; returns the (reused) output tensor."""
         with torch.cuda.device(self.device):

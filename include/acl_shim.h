@@ -119,6 +119,11 @@ SPFA_API aclnnStatus spfaSetSharedScoring(int enable);
  * workgroups of four, 0 (default) = the planner's choice (eight, unless a fused launch hands a workgroup more items
  * than can be scored ahead).  Outputs do not depend on it beyond fp32 rounding.  Stays until changed. */
 SPFA_API aclnnStatus spfaSetWorkgroupGeometry(int geometry);
+/* Fused op, one q head per pass, more items than resident workgroups: the work queue hands out groups of up to 8
+ * consecutive sequences of one kv head and their rows are scored in one pass over the head's centroids, beside the page
+ * stream of the group before (one pass per item otherwise).  Outputs do not depend on the setting.  0 turns it off.
+ * Default on.  Stays until changed. */
+SPFA_API aclnnStatus spfaSetBatchedSelection(int enable);
 /* page size of the two ops without a blockSize attribute (CentSelect, SelectPosition); the reference
  * compiles in 128 (cent_select.cpp:17, select_position.cpp:112).  Default 128. */
 SPFA_API aclnnStatus spfaSetPageSize(int64_t pageSize);
@@ -170,6 +175,10 @@ SPFA_API aclnnStatus spfaSetWorkspacePersistent(aclOpExecutor* executor, int ena
  * a graph (a replay may run on any stream), launches on the hipStreamPerThread handle and launches beyond the sixteen
  * slots keep their counters in the caller's workspace behind the zeroing kernel, as with 0. */
 SPFA_API aclnnStatus spfaSetLibraryCounters(int enable);
+/* The launch plan of an executor of the two attention ops as one line of text (kernel form, workgroup geometry, rows per
+ * pass, items scored ahead, super-items, page-list split, sharing of last items, resident workgroups, LDS and workspace
+ * bytes): for logs and tests.  Returns the number of characters written, -1 on a bad argument. */
+SPFA_API int spfaDescribeExecutor(const aclOpExecutor* executor, char* buf, uint64_t n);
 /* Kernels the library has enqueued (or recorded into a graph) since it was loaded, over all threads and devices: the
  * difference around a call tells how many kernels that call was. */
 SPFA_API uint64_t spfaKernelLaunches(void);
