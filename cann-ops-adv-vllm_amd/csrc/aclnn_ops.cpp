@@ -266,6 +266,11 @@ aclnnStatus hip_fail(hipError_t e, const char* what) {
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
+// library-owned counters (defined with the attention ops below)
+static bool stream_is_capturing(hipStream_t stream);
+static void* stream_slot(hipStream_t stream, uint64_t zero_bytes, bool* needs_zero);
+static void stream_slot_failed(hipStream_t stream);
+
 aclTensor* aclCreateTensor(const int64_t* viewDims, uint64_t viewDimsNum, aclDataType dataType, const int64_t* stride,
                            int64_t offset, aclFormat, const int64_t*, uint64_t, void* tensorData) {
     if (viewDimsNum > 0 && viewDims == nullptr) return nullptr;
@@ -356,8 +361,11 @@ aclnnStatus spfaSetSharedPrefix(const void* keyPrefix, const void* valuePrefix, 
     return ACLNN_SUCCESS;
 }
 aclnnStatus spfaSetAntiquantMode(int64_t mode) {
-    if (mode != 0 && mode != 1)
-        return fail(ACLNN_ERR_PARAM_INVALID, "antiquant mode %lld: 0 (per channel / per tensor) or 1 (per token)", (long long)mode);
+    if (mode < 0 || mode > 3)
+        return fail(ACLNN_ERR_PARAM_INVALID,
+                    "antiquant mode %lld: 0 (per channel / per tensor), 1 (per token), 2 (per tensor and head) or 3 (per token "
+                    "and head); the modes that keep the parameters in page-attention layout (4, 5) are not supported",
+                    (long long)mode);
     g_antiq_mode = (int)mode;
     return ACLNN_SUCCESS;
 }
@@ -565,11 +573,27 @@ aclnnStatus aclnnCentSelectGetWorkspaceSize(const aclTensor* query, const aclTen
 aclnnStatus aclnnCentSelect(void*, uint64_t, aclOpExecutor* executor, aclrtStream stream) {
     REQUIRE_PTR(executor, "executor");
     REQUIRE(executor->op == kOpCentSelect, "executor was not created by aclnnCentSelectGetWorkspaceSize");
-    const spfa::CentParams& p = executor->cent;
+    spfa::CentParams p = executor->cent;
     hipError_t err = hipSuccess;
-    if (p.B > 0)   // the per-batch maximum is accumulated with atomicMax
+    // The per-batch maximum over a sequence's Hq rows, which different workgroups select.  With a slot of library-owned
+    // counters for this stream (see stream_slot): a running maximum and an arrival count per sequence, the row that
+    // completes a sequence stores the result and clears the two words again — one kernel.  Otherwise (launch being
+    // captured, batch beyond the slot, no slot left): atomicMax straight into the output, zeroed by a kernel in front.
+    auto up256 = [](uint64_t x) { return (x + 255) & ~255ull; };
+    const uint64_t slot_bytes = up256((uint64_t)p.B * 4) + (uint64_t)p.B * 8;
+    bool needs_zero = false, in_slot = false;
+    if (p.B > 0 && !stream_is_capturing((hipStream_t)stream)) {
+        if (void* slot = stream_slot((hipStream_t)stream, slot_bytes, &needs_zero)) {
+            in_slot = true;
+            if (needs_zero) err = spfa::launch_zero(slot, spfa::kScratchSlotBytes, nullptr, 0, (hipStream_t)stream);
+            p.batch_arrive = (unsigned*)slot;
+            p.batch_max = (unsigned long long*)((char*)slot + up256((uint64_t)p.B * 4));
+        }
+    }
+    if (!in_slot && p.B > 0)
         err = spfa::launch_zero(p.max_page_position_length, (size_t)p.B * spfa::kLenPad * 8, nullptr, 0, (hipStream_t)stream);
     if (err == hipSuccess) err = spfa::launch_cent_select(p, (hipStream_t)stream);
+    if (err != hipSuccess && in_slot) stream_slot_failed((hipStream_t)stream);
     return finish(executor, err, "cent_select launch");
 }
 
@@ -648,20 +672,37 @@ static aclnnStatus plan_attention(spfa::AttnParams& p, const aclTensor* query, c
             "head dim %d with %d-byte KV elements is not supported (row bytes must be 64, 128, 256, 512 or 1024)", D, es);
     REQUIRE(kd[0] > 0 && kd[0] <= 0x7fffffff, "KV cache has no blocks");
 
-    REQUIRE(antiq_mode == 0 || quant, "a per-token antiquant mode needs an int8 KV cache");
-    if (quant && antiq_mode == 1) {
-        // per token (…_tiling.cc:733-765, …Us2.h:2039-2043): float32 [2, B, S], key parameters first; S is checked once
-        // the table width is known
+    REQUIRE(antiq_mode == 0 || quant, "antiquant modes other than 0 need an int8 KV cache");
+    if (quant && (antiq_mode == 1 || antiq_mode == 3)) {
+        // per token (…_tiling.cc:733-765, …Us2.h:2039-2043): float32 [2, B, S], key parameters first; per token and head
+        // (mode 3, …_tiling_check.cc:466-487, …Us2.h:2203-2206): [2, B, Hkv, S].  S is checked once the table width is known
+        const size_t nd = antiq_mode == 3 ? 4 : 3;
         REQUIRE(!absent(antiquantScale), "int8 KV cache needs antiquantScale");
-        REQUIRE(antiquantScale->dtype == ACL_FLOAT && antiquantScale->dims.size() == 3 && antiquantScale->dims[0] == 2 &&
+        REQUIRE(antiquantScale->dtype == ACL_FLOAT && antiquantScale->dims.size() == nd && antiquantScale->dims[0] == 2 &&
                     is_contiguous(antiquantScale) && antiquantScale->data,
-                "per-token antiquantScale must be a contiguous float32 [2, B, S] tensor (…_tiling.cc:733-765)");
+                "per-token antiquantScale must be a contiguous float32 %s tensor (…_tiling.cc:733-765)",
+                antiq_mode == 3 ? "[2, B, Hkv, S]" : "[2, B, S]");
+        REQUIRE(antiq_mode != 3 || antiquantScale->dims[2] == Hkv,
+                "per-token-head antiquantScale holds %lld heads, the op %d kv heads (…_tiling_check.cc:476)",
+                (long long)antiquantScale->dims[2], Hkv);
         if (!absent(antiquantOffset))
             REQUIRE(antiquantOffset->dtype == ACL_FLOAT && antiquantOffset->dims == antiquantScale->dims &&
                         is_contiguous(antiquantOffset) && antiquantOffset->data,
                     "per-token antiquantOffset must have antiquantScale's shape and dtype");
         p.antiq_per_token = 1;
-        p.antiq_s = antiquantScale->dims[2];
+        p.antiq_s = antiquantScale->dims[nd - 1];
+        p.antiq_tok_heads = antiq_mode == 3 ? Hkv : 0;
+    } else if (quant && antiq_mode == 2) {
+        // per tensor and head (…_tiling_check.cc:488-497: one value per kv head; here key values first, then value values)
+        REQUIRE(!absent(antiquantScale), "int8 KV cache needs antiquantScale");
+        REQUIRE(antiquantScale->dtype == query->dtype && antiquantScale->dims.size() == 2 && antiquantScale->dims[0] == 2 &&
+                    antiquantScale->dims[1] == Hkv && is_contiguous(antiquantScale),
+                "per-tensor-head antiquantScale must be [2, Hkv = %d] in the query dtype (…_tiling_check.cc:488-497)", Hkv);
+        if (!absent(antiquantOffset))
+            REQUIRE(antiquantOffset->dtype == query->dtype && antiquantOffset->dims == antiquantScale->dims &&
+                        is_contiguous(antiquantOffset),
+                    "antiquantOffset must have antiquantScale's shape and the query dtype");
+        p.antiq_per_tensor = 2;
     } else if (quant) {
         REQUIRE(!absent(antiquantScale), "int8 KV cache needs antiquantScale");
         // [2]: one key and one value parameter for the whole tensor (…_tiling.cc:785-793; the value parameter is
@@ -1062,7 +1103,7 @@ static void plan_workspace(aclOpExecutor* e) {
 // from data_base.  Both are the caller's workspace unless the zeroed part lives in library-owned memory.  zero: enqueue
 // the zeroing of that part first (needed unless it is known to be in the state the previous launch left it in).
 static hipError_t bind_workspace(const aclOpExecutor* e, spfa::AttnParams& p, void* zero_base, void* data_base,
-                                 hipStream_t stream, bool zero) {
+                                 hipStream_t stream, bool zero, uint64_t zero_bytes = 0) {
     if ((((uintptr_t)zero_base | (uintptr_t)data_base) & 15) != 0) return hipErrorInvalidValue;   // 64-bit atomics, 16-byte boards
     auto up256 = [](uint64_t x) { return (x + 255) & ~255ull; };
     char* const zb = (char*)zero_base;
@@ -1077,7 +1118,8 @@ static hipError_t bind_workspace(const aclOpExecutor* e, spfa::AttnParams& p, vo
     p.split_partials = (float*)(db + e->ws_parts_off);
     p.tail_data = db + e->ws_tail_off;
     p.pg_keys = (uint32_t*)(db + e->ws_pgkeys_off);
-    return zero ? spfa::launch_zero(zero_base, e->ws_zero_bytes, nullptr, 0, stream) : hipSuccess;
+    // (a slot of the library is zeroed as a whole the first time it is used: later launches with other plans rely on it)
+    return zero ? spfa::launch_zero(zero_base, zero_bytes ? zero_bytes : e->ws_zero_bytes, nullptr, 0, stream) : hipSuccess;
 }
 
 static bool stream_is_capturing(hipStream_t stream) {
@@ -1116,6 +1158,19 @@ static void* stream_slot(hipStream_t stream, uint64_t zero_bytes, bool* needs_ze
             s.zeroed = true;   // the zeroing is enqueued on this stream in front of the first launch that uses the slot
             return (char*)base + spfa::kScratchSlotsOff + (size_t)i * spfa::kScratchSlotBytes;
         }
+    }
+    // Every slot belongs to some stream: take over the slot of a stream that is idle right now — everything it was
+    // given has run to completion, and every launch leaves its slot clean.  (A stream that no longer exists answers the
+    // query with an error and keeps its slot: nothing is known about work it may still have had in flight.)
+    for (int i = 0; i < spfa::kScratchSlots; ++i) {
+        StreamSlot& s = g_slots[dev][i];
+        if (!s.zeroed) continue;
+        if (hipStreamQuery((hipStream_t)(s.key - 1)) == hipSuccess) {
+            s.key = key;
+            *needs_zero = false;
+            return (char*)base + spfa::kScratchSlotsOff + (size_t)i * spfa::kScratchSlotBytes;
+        }
+        (void)hipGetLastError();
     }
     return nullptr;
 }
@@ -1260,7 +1315,8 @@ aclnnStatus aclnnSparsePagedAttention(void* workspace, uint64_t workspaceSize, a
         if (ds != ACLNN_SUCCESS) { if (!executor->repeatable) delete executor; return ds; }
     }
     const ZeroPlace zp = place_zeroed_part(executor, workspace, (hipStream_t)stream);
-    hipError_t err = bind_workspace(executor, p, zp.base, workspace, (hipStream_t)stream, zp.zero);
+    hipError_t err = bind_workspace(executor, p, zp.base, workspace, (hipStream_t)stream, zp.zero,
+                                    zp.slot ? spfa::kScratchSlotBytes : 0);
     if (err == hipSuccess && !executor->act_seq.empty()) {
         // Per-batch lengths travel to the workspace as kernel arguments: copied when the launch is enqueued (or
         // captured into a graph), so no host memory has to outlive this call.
@@ -1366,7 +1422,8 @@ aclnnStatus aclnnSparsePagedFusionAttention(void* workspace, uint64_t workspaceS
         if (ds != ACLNN_SUCCESS) { if (!executor->repeatable) delete executor; return ds; }
     }
     const ZeroPlace zp = place_zeroed_part(executor, workspace, (hipStream_t)stream);
-    hipError_t err = bind_workspace(executor, p, zp.base, workspace, (hipStream_t)stream, zp.zero);
+    hipError_t err = bind_workspace(executor, p, zp.base, workspace, (hipStream_t)stream, zp.zero,
+                                    zp.slot ? spfa::kScratchSlotBytes : 0);
     if (err == hipSuccess) err = spfa::launch_attention(p, (hipStream_t)stream);
     launch_outcome(executor, zp, (hipStream_t)stream, err);
     return finish(executor, err, "sparse_paged_fusion_attention launch");

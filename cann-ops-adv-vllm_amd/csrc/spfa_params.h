@@ -38,6 +38,11 @@ struct CentParams {
     int32_t* page_position;        // [B, Hq, P]
     int32_t* page_position_length; // [B, Hq, 8]
     unsigned long long* max_page_position_length; // [B, 8] (int64, non negative)
+    // per-sequence arrival counts and running maxima in zeroed memory that the launch leaves zeroed (the row that
+    // completes a sequence's Hq rows stores the maximum and clears both words); null: atomicMax straight into
+    // max_page_position_length, which then has to be zeroed before the launch
+    unsigned* batch_arrive;        // [B]
+    unsigned long long* batch_max; // [B]
     size_t lds_bytes;
 };
 
@@ -90,12 +95,14 @@ struct AttnParams {
     float scale;
     const void* antiq_scale;   // [2, Hkv*D] in q dtype, or null
     const void* antiq_offset;  // [2, Hkv*D] in q dtype, or null
-    int antiq_per_tensor;      // 1: antiq_scale / antiq_offset are [2] (one key and one value parameter)
+    int antiq_per_tensor;      // layout of antiq_scale / antiq_offset: 0 per channel [2, Hkv, D], 1 per tensor [2] (one
+                               // key and one value parameter), 2 per kv head [2, Hkv]
     // 1: per-token parameters (…Us2.h:2039-2041, 3711-3822): antiq_scale / antiq_offset are float32 [2, B, antiq_s], one
     // key and one value parameter per column of the gathered sequence (the columns of pse / amask); every q head runs
     // as a pass of its own
     int antiq_per_token;
     long long antiq_s;
+    int antiq_tok_heads;       // per-token parameters with a row per kv head, float32 [2, B, Hkv, antiq_s]: Hkv, else 0
     // Additive score bias and boolean mask over the columns of the gathered sequence (column = list slot * block_size +
     // token in page), …Us2.h:3366-3404.  Either one makes every q head run as a pass of its own.
     const void* pse;           // [pse_b, Hq, 1, pse_s] in q dtype, or null

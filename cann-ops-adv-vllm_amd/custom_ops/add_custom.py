@@ -19,7 +19,9 @@ out (sparse_paged_fusion_attention_split_Bbn2s2_Us2.h:1418-1439, 3130-3159):
                             K / V rows of a prefix that every row attends in front of its pages: [1, S, Hkv * D] for a
                             [blocks, block_size, Hkv * D] cache, [1, Hkv, S, D] for a [blocks, Hkv, block_size, D] cache
   antiquant_mode            0: antiquant_scale / antiquant_offset per channel [2, Hkv, D] or per tensor [2] (query dtype);
-                            1: per token, float32 [2, B, S] over the columns of the gathered sequence
+                            1: per token, float32 [2, B, S] over the columns of the gathered sequence;
+                            2: per tensor and kv head, [2, Hkv] (query dtype); 3: per token and kv head, float32
+                            [2, B, Hkv, S] (the reference's modes 4 and 5 keep the parameters in pages: not supported)
 """
 from __future__ import annotations
 

@@ -143,7 +143,11 @@ SPFA_API aclnnStatus spfaSetTokenPositions(int enable);
  * or [2] (per tensor) in the query dtype.  1: per token — float32 [2, B, S] with S >= blocktable columns * blockSize
  * (+ the shared prefix length), key parameters first: K_t = (k_t + offset[0, b, c]) * scale[0, b, c] and likewise V with
  * index 1, c being the token's column in the gathered sequence (prefix tokens, then list slot * blockSize + token), as
- * for pseShift / attenMask (sparse_paged_fusion_attention_split_Bbn2s2_Us2.h:2039-2043, 2262-2266, 3711-3822). */
+ * for pseShift / attenMask (sparse_paged_fusion_attention_split_Bbn2s2_Us2.h:2039-2043, 2262-2266, 3711-3822).
+ * 2: per tensor and kv head — [2, Hkv] in the query dtype, one key and one value parameter per kv head
+ * (sparse_paged_fusion_attention_tiling_check.cc:488-497; the reference takes key and value parameters as two [Hkv]
+ * tensors, here they are the two rows of one).  3: per token and kv head — float32 [2, B, Hkv, S] (:466-487, kernel
+ * offsets …Us2.h:2203-2206).  Modes 4 and 5 of the reference (parameters in page-attention layout) are refused. */
 SPFA_API aclnnStatus spfaSetAntiquantMode(int64_t mode);
 /* One-shot: the next aclnnSparsePagedAttentionGetWorkspaceSize / aclnnSparsePagedFusionAttentionGetWorkspaceSize on
  * this thread also writes the softmax log-sum-exp of every output row, ln(sum_t exp(score_t)) as float32, to this
@@ -172,8 +176,9 @@ SPFA_API aclnnStatus spfaSetWorkspacePersistent(aclOpExecutor* executor, int ena
  * library owns — one slot per (device, stream), sixteen per device, zeroed once and left zeroed by every launch — so
  * a call with any caller workspace enqueues exactly one kernel and only the data areas of the workspace are used.
  * Launches on one stream are ordered, which is what makes sharing a slot safe.  Launches that are being captured into
- * a graph (a replay may run on any stream), launches on the hipStreamPerThread handle and launches beyond the sixteen
- * slots keep their counters in the caller's workspace behind the zeroing kernel, as with 0. */
+ * a graph (a replay may run on any stream), launches on the hipStreamPerThread handle and launches that find all sixteen
+ * slots owned by streams with work in flight keep their counters in the caller's workspace behind the zeroing kernel, as
+ * with 0.  CentSelect keeps its per-sequence maxima the same way (one kernel instead of two). */
 SPFA_API aclnnStatus spfaSetLibraryCounters(int enable);
 /* The launch plan of an executor of the two attention ops as one line of text (kernel form, workgroup geometry, rows per
  * pass, items scored ahead, super-items, page-list split, sharing of last items, resident workgroups, LDS and workspace

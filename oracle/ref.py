@@ -228,6 +228,8 @@ def sparse_paged_attention(q, key_cache, value_cache, block_table, block_positio
     antiquant_mode=1 (per token, …Us2.h:2039-2043, 3711-3822): antiquant_scale / antiquant_offset are float32
     [2, B, S] over the columns of the gathered sequence (as pse_shift / atten_mask): K_t = (k_t + off[0, b, c]) *
     scale[0, b, c], V_t = (v_t + off[1, b, c]) * scale[1, b, c].  exact mode.
+    antiquant_mode=2 (per tensor and head, …_tiling_check.cc:488-497): [2, Hkv] in the query dtype, one key and one value
+    parameter per kv head.  antiquant_mode=3 (per token and head, :466-487, …Us2.h:2203-2206): float32 [2, B, Hkv, S].
 
     key_shared_prefix / value_shared_prefix ([1, S, Hkv * D] | [1, S, Hkv, D] for a BSH cache, [1, Hkv, S, D] for
     BNSD; the KV dtype, int8 with the same antiquant parameters): every row attends the first shared_prefix_len
@@ -252,15 +254,19 @@ def sparse_paged_attention(q, key_cache, value_cache, block_table, block_positio
     P = bp.shape[2]
     bt = np.asarray(block_table)
     quant = antiquant_scale is not None
-    per_token = quant and antiquant_mode == 1
+    per_token = quant and antiquant_mode in (1, 3)
     assert not per_token or exact
     if per_token:
-        pt_s = np.asarray(antiquant_scale, dtype=np.float64).reshape(2, B, -1)
-        pt_o = None if antiquant_offset is None else np.asarray(antiquant_offset, dtype=np.float64).reshape(2, B, -1)
+        # [2, B, S], or with a row per kv head (mode 3) [2, B, Hkv, S]: both as [2, B, heads, S]
+        heads = Hkv if antiquant_mode == 3 else 1
+        pt_s = np.asarray(antiquant_scale, dtype=np.float64).reshape(2, B, heads, -1)
+        pt_o = None if antiquant_offset is None else np.asarray(antiquant_offset, dtype=np.float64).reshape(2, B, heads, -1)
         a_o = None
     elif quant:
         def _params(t):
             t = np.asarray(t, dtype=np.float32)
+            if antiquant_mode == 2:     # one value per kv head
+                return np.broadcast_to(t.reshape(2, Hkv, 1), (2, Hkv, D))
             if t.size == 2:
                 return np.broadcast_to(t.reshape(2, 1, 1), (2, Hkv, D))
             return t.reshape(2, Hkv, D)
@@ -336,11 +342,12 @@ def sparse_paged_attention(q, key_cache, value_cache, block_table, block_positio
                 V = np.concatenate(vs).astype(np.float64)
                 col = np.concatenate(cols)
                 if per_token:
+                    ph = n2 if antiquant_mode == 3 else 0
                     if pt_o is not None:
-                        K = K + pt_o[0, b, col][:, None]
-                        V = V + pt_o[1, b, col][:, None]
-                    K = K * pt_s[0, b, col][:, None]
-                    V = V * pt_s[1, b, col][:, None]
+                        K = K + pt_o[0, b, ph, col][:, None]
+                        V = V + pt_o[1, b, ph, col][:, None]
+                    K = K * pt_s[0, b, ph, col][:, None]
+                    V = V * pt_s[1, b, ph, col][:, None]
                 s = (K @ qv) * np.float64(scale)
                 if pse is not None:
                     s = s + pse[b if pse.shape[0] > 1 else 0, h, 0, col].astype(np.float64)

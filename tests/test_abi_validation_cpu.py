@@ -277,7 +277,8 @@ def test_one_shot_extras_are_validated_and_consumed(lib):
     st, _, msg = attention(lib, pse=tensor(lib, (1, Hq, 1, 24 * 128), F16))
     assert st == PARAM_INVALID and "prefix + sMax" in msg
     # antiquant mode 1: float32 [2, B, S] parameters and an int8 cache
-    assert lib.spfaSetAntiquantMode(2) == PARAM_INVALID
+    assert lib.spfaSetAntiquantMode(4) == PARAM_INVALID      # parameters in page-attention layout: not supported
+    assert lib.spfaSetAntiquantMode(-1) == PARAM_INVALID
     assert lib.spfaSetAntiquantMode(1) == 0
     st, _, msg = attention(lib)
     assert st == PARAM_INVALID and "int8 KV cache" in msg
@@ -290,6 +291,20 @@ def test_one_shot_extras_are_validated_and_consumed(lib):
     assert lib.spfaSetAntiquantMode(1) == 0
     assert attention(lib, kv_dtype=I8, antiq=tensor(lib, (2, B, 24 * 128), F32))[0] == 0
     assert attention(lib, kv_dtype=I8, antiq=tensor(lib, (2, 2, 128), F16))[0] == 0     # the mode was one-shot
+    # mode 2: [2, Hkv] in the query dtype; mode 3: float32 [2, B, Hkv, S]  (the helper's op has 2 kv heads)
+    assert lib.spfaSetAntiquantMode(2) == 0
+    st, _, msg = attention(lib, kv_dtype=I8, antiq=tensor(lib, (2, 2, 128), F16))
+    assert st == PARAM_INVALID and "[2, Hkv = 2]" in msg
+    assert lib.spfaSetAntiquantMode(2) == 0
+    assert attention(lib, kv_dtype=I8, antiq=tensor(lib, (2, 2), F16))[0] == 0
+    assert lib.spfaSetAntiquantMode(3) == 0
+    st, _, msg = attention(lib, kv_dtype=I8, antiq=tensor(lib, (2, B, 24 * 128), F32))
+    assert st == PARAM_INVALID and "[2, B, Hkv, S]" in msg
+    assert lib.spfaSetAntiquantMode(3) == 0
+    st, _, msg = attention(lib, kv_dtype=I8, antiq=tensor(lib, (2, B, 3, 24 * 128), F32))
+    assert st == PARAM_INVALID and "holds 3 heads" in msg
+    assert lib.spfaSetAntiquantMode(3) == 0
+    assert attention(lib, kv_dtype=I8, antiq=tensor(lib, (2, B, 2, 24 * 128), F32))[0] == 0
     # the geometry knob stays until changed and accepts 0, 1, 2 only
     assert lib.spfaSetWorkgroupGeometry(3) == PARAM_INVALID
     for g in (1, 2, 0):

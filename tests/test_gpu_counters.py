@@ -182,3 +182,53 @@ def test_python_surface_is_unchanged_by_the_setting():
                 assert float((sep - out).abs().max()) <= 1e-3 * float(out.abs().max())   # other kernel form (one q head per pass)
         finally:
             _abi.spfaSetLibraryCounters(1)
+
+
+def test_cent_select_is_one_kernel_with_library_counters():
+    """cent_select accumulates the per-sequence maximum over rows that different workgroups select: with the stream's
+    slot of library-owned counters the launch is one kernel and leaves the slot clean; without (setting off, or a launch
+    that is being captured) a kernel zeroes the output first.  Same results either way, against the oracle."""
+    import custom_ops
+    import gpu_helpers as H
+    from custom_ops import _abi
+    from oracle import ref
+    B, Hq, Hkv, D, C, k, bs, max_page = 37, 16, 4, 128, 512, 16, 128, 300
+    seq_lens = [int(x) for x in datagen.rng_for(5).integers(1, max_page * bs, size=B)]
+    q, l1 = datagen.cent_case(61, B, Hq, Hkv, D, C, grid=True)
+    ids, table, seq = datagen.page_case(61, Hkv, C, 400, B, max_page, seq_lens)
+    wpos, wlen, wmax, _ = ref.cent_select(q, l1, ids, table, seq, k, bs, 256)
+    dv = [H.dev(x) for x in (q, l1, ids, table, seq)]
+
+    def run(stream=None):
+        with torch.cuda.stream(stream) if stream is not None else torch.cuda.stream(torch.cuda.current_stream()):
+            n0 = int(_abi.spfaKernelLaunches())
+            pos, plen, pmax = custom_ops.cent_select(*dv, k=k)
+            n = int(_abi.spfaKernelLaunches()) - n0
+        torch.cuda.synchronize()
+        assert np.array_equal(pos.cpu().numpy(), wpos) and np.array_equal(plen.cpu().numpy(), wlen)
+        assert np.array_equal(pmax.cpu().numpy(), wmax)
+        return n
+
+    assert run() <= 2                      # (the first use of a stream's slot zeroes it)
+    assert [run() for _ in range(3)] == [1, 1, 1]
+    side = torch.cuda.Stream()
+    assert run(side) <= 2 and run(side) == 1 and run() == 1
+    _abi.check(_abi.spfaSetLibraryCounters(0), "spfaSetLibraryCounters")
+    try:
+        assert run() == 2
+    finally:
+        _abi.spfaSetLibraryCounters(1)
+    assert run() == 1
+    # a sequence count beyond what a slot holds falls back by itself
+    Bbig = 6000
+    qb = torch.zeros((Bbig, 4, 64), dtype=torch.float16, device=H.DEV)
+    l1b = torch.zeros((4, 128, 64), dtype=torch.float16, device=H.DEV)
+    idsb = torch.zeros((4, 8), dtype=torch.int32, device=H.DEV)
+    tableb = torch.zeros((Bbig, 2), dtype=torch.int32, device=H.DEV)
+    seqb = torch.full((Bbig,), 200, dtype=torch.int32, device=H.DEV)
+    n0 = int(_abi.spfaKernelLaunches())
+    pos, plen, pmax = custom_ops.cent_select(qb, l1b, idsb, tableb, seqb, k=8)
+    torch.cuda.synchronize()
+    assert int(_abi.spfaKernelLaunches()) - n0 == 2
+    # all scores tie: the 8 lowest cluster ids are taken, every page has cluster id 0 -> both pages selected
+    assert bool((plen == 2).all()) and bool((pmax == 2 * 128).all())

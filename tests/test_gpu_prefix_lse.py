@@ -374,7 +374,7 @@ def test_per_token_antiquant_errors(H):
     table = H.dev(np.zeros((B, 4), np.int32))
     pos = H.dev(np.zeros((B, Hq, 4), np.int32))
     good = H.dev(np.ones((2, B, 4 * bs), np.float32))
-    with pytest.raises(AclError, match="needs an int8 KV cache"):
+    with pytest.raises(AclError, match="need an int8 KV cache"):
         H.call_attention(q, kv16, kv16, table, pos, [128], Hq, Hq, 1.0, bs, antiquant_mode=1)
     with pytest.raises(AclError, match="float32 \\[2, B, S\\]"):
         H.call_attention(q, kv8, kv8, table, pos, [128], Hq, Hq, 1.0, bs, antiquant_mode=1,
@@ -383,7 +383,14 @@ def test_per_token_antiquant_errors(H):
         H.call_attention(q, kv8, kv8, table, pos, [128], Hq, Hq, 1.0, bs, antiquant_mode=1,
                          antiq_scale=H.dev(np.ones((2, B, 4 * bs - 1), np.float32)))
     with pytest.raises(AclError, match="antiquant mode"):
+        H.call_attention(q, kv8, kv8, table, pos, [128], Hq, Hq, 1.0, bs, antiquant_mode=4, antiq_scale=good)
+    with pytest.raises(AclError, match="\\[2, Hkv = 4\\]"):
         H.call_attention(q, kv8, kv8, table, pos, [128], Hq, Hq, 1.0, bs, antiquant_mode=2, antiq_scale=good)
+    with pytest.raises(AclError, match="float32 \\[2, B, Hkv, S\\]"):
+        H.call_attention(q, kv8, kv8, table, pos, [128], Hq, Hq, 1.0, bs, antiquant_mode=3, antiq_scale=good)
+    with pytest.raises(AclError, match="holds 3 heads"):
+        H.call_attention(q, kv8, kv8, table, pos, [128], Hq, Hq, 1.0, bs, antiquant_mode=3,
+                         antiq_scale=H.dev(np.ones((2, B, 3, 4 * bs), np.float32)))
     # the mode was one-shot: a per-channel call right after works with per-channel shapes
     out = H.call_attention(q, kv8, kv8, table, pos, [128], Hq, Hq, 1.0, bs,
                            antiq_scale=H.dev(np.ones((2, Hq, D), np.float16)))
@@ -408,3 +415,90 @@ def test_per_token_antiquant_in_a_large_launch(H):
                            softmax_lse=lse, key_shared_prefix=H.dev(kp), value_shared_prefix=H.dev(vp))
     assert float(parity.rel_err(H.f32(out), want).max()) <= TOL
     _lse_close(lse.cpu().numpy(), wlse)
+
+
+@pytest.mark.parametrize("Hq,Hkv,rows,D,bs,layout,with_offset,fused", [
+    (8, 8, "kv", 128, 128, "BSH", True, False),
+    (8, 2, "kv", 128, 128, "BSH", True, False),          # a group pass on the matrix cores
+    (8, 2, "q", 128, 32, "BNSD", False, False),
+    (32, 4, "kv", 64, 64, "BSH", True, False),
+    (8, 2, "kv", 128, 128, "BSH", True, True),
+])
+def test_per_head_antiquant_vs_oracle(H, Hq, Hkv, rows, D, bs, layout, with_offset, fused):
+    """Antiquant mode 2: one key and one value parameter per kv head, [2, Hkv] in the query dtype
+    (sparse_paged_fusion_attention_tiling_check.cc:488-497).  Parity unpinned (the oracle restates the kernel source);
+    the per-channel form of the same numbers is an independent check."""
+    rng, q, k, v, table, pos, act = _case(1200 + Hq + D, "i8", Hq, Hkv, rows, D, bs, layout=layout)
+    B = q.shape[0]
+    sc = (rng.random((2, Hkv)) * 0.02 + 0.002).astype(np.float16)
+    of = (rng.standard_normal((2, Hkv)) * 4.0).astype(np.float16) if with_offset else None
+    scale = D ** -0.5
+    chan_s = np.broadcast_to(sc[:, :, None], (2, Hkv, D)).copy()
+    chan_o = None if of is None else np.broadcast_to(of[:, :, None], (2, Hkv, D)).copy()
+    if fused:
+        C, topk = 256, 8
+        _, l1 = datagen.cent_case(3, B, Hq, Hkv, D, C, grid=True)
+        ids = rng.integers(0, C, size=(Hkv, k.shape[0])).astype(np.int32)
+        seq = np.array(act, np.int32)
+        want, wpos, wlen, wmax = ref.sparse_paged_fusion_attention(q, k, v, table, l1, ids, seq, Hq, Hkv, scale, bs, topk, 256,
+                                                                   kv_layout=layout, antiquant_scale=sc, antiquant_offset=of,
+                                                                   antiquant_mode=2)
+        out, gpos, _, _ = H.call_fusion(H.dev(q), H.dev(k), H.dev(v), H.dev(table), H.dev(l1), H.dev(ids), H.dev(seq), Hq, Hkv,
+                                        scale, bs, topk, out_dtype=torch.float32, antiq_scale=H.dev(sc),
+                                        antiq_offset=None if of is None else H.dev(of), antiquant_mode=2)
+        assert np.array_equal(gpos.cpu().numpy(), wpos)
+        assert float(parity.rel_err(H.f32(out), want).max()) <= TOL
+        return
+    want, wlse = ref.sparse_paged_attention(q, k, v, table, pos, act, Hq, Hkv, scale, bs, layout, antiquant_scale=sc,
+                                            antiquant_offset=of, antiquant_mode=2, return_lse=True)
+    lse = torch.empty((B, Hq), dtype=torch.float32, device=H.DEV)
+    args = (H.dev(q), H.dev(k), H.dev(v), H.dev(table), H.dev(pos), torch.tensor(act), Hq, Hkv, scale, bs)
+    out = H.call_attention(*args, out_dtype=torch.float32, antiq_scale=H.dev(sc),
+                           antiq_offset=None if of is None else H.dev(of), antiquant_mode=2, softmax_lse=lse)
+    assert float(parity.rel_err(H.f32(out), want).max()) <= TOL
+    _lse_close(lse.cpu().numpy(), wlse)
+    # the same numbers spelled out per channel: the same kernel, the same arithmetic
+    chan = H.call_attention(*args, out_dtype=torch.float32, antiq_scale=H.dev(chan_s),
+                            antiq_offset=None if chan_o is None else H.dev(chan_o))
+    assert float((chan - out).abs().max()) <= 2e-6 * float(chan.abs().max())
+
+
+@pytest.mark.parametrize("Hq,Hkv,rows,D,bs,layout,with_offset,n_pre", [
+    (8, 8, "kv", 128, 128, "BSH", True, 0),
+    (8, 2, "kv", 128, 128, "BSH", True, 0),
+    (8, 2, "q", 128, 32, "BNSD", False, 0),
+    (8, 2, "kv", 128, 128, "BSH", True, 200),
+])
+def test_per_token_head_antiquant_vs_oracle(H, Hq, Hkv, rows, D, bs, layout, with_offset, n_pre):
+    """Antiquant mode 3: per token and kv head, float32 [2, B, Hkv, S] (…_tiling_check.cc:466-487, kernel offsets
+    sparse_paged_fusion_attention_split_Bbn2s2_Us2.h:2203-2206).  Parity unpinned; parameters that are the same for every
+    head must give what mode 1 gives."""
+    rng, q, k, v, table, pos, act = _case(1300 + Hq + D, "i8", Hq, Hkv, rows, D, bs, layout=layout)
+    B = q.shape[0]
+    S = table.shape[1] * bs + n_pre + 5
+    sc = (rng.random((2, B, Hkv, S)) * 0.02 + 0.002).astype(np.float32)
+    of = (rng.standard_normal((2, B, Hkv, S)) * 4.0).astype(np.float32) if with_offset else None
+    pre_kw, pre_okw = {}, {}
+    if n_pre:
+        kp, vp = _prefix(rng, "i8", n_pre, Hkv, D, layout)
+        pre_kw = dict(key_shared_prefix=H.dev(kp), value_shared_prefix=H.dev(vp))
+        pre_okw = dict(key_shared_prefix=kp, value_shared_prefix=vp)
+    scale = D ** -0.5
+    want, wlse = ref.sparse_paged_attention(q, k, v, table, pos, act, Hq, Hkv, scale, bs, layout, antiquant_scale=sc,
+                                            antiquant_offset=of, antiquant_mode=3, return_lse=True, **pre_okw)
+    lse = torch.empty((B, Hq), dtype=torch.float32, device=H.DEV)
+    args = (H.dev(q), H.dev(k), H.dev(v), H.dev(table), H.dev(pos), torch.tensor(act), Hq, Hkv, scale, bs)
+    out = H.call_attention(*args, out_dtype=torch.float32, antiq_scale=H.dev(sc),
+                           antiq_offset=None if of is None else H.dev(of), antiquant_mode=3, softmax_lse=lse, **pre_kw)
+    assert float(parity.rel_err(H.f32(out), want).max()) <= TOL
+    _lse_close(lse.cpu().numpy(), wlse)
+    # head-independent parameters: mode 3 == mode 1, bit for bit (the same kernel reads the same numbers)
+    sc1 = sc[:, :, 0].copy()
+    of1 = None if of is None else of[:, :, 0].copy()
+    sc3 = np.broadcast_to(sc1[:, :, None, :], sc.shape).copy()
+    of3 = None if of1 is None else np.broadcast_to(of1[:, :, None, :], sc.shape).copy()
+    a = H.call_attention(*args, out_dtype=torch.float32, antiq_scale=H.dev(sc1),
+                         antiq_offset=None if of1 is None else H.dev(of1), antiquant_mode=1, **pre_kw)
+    b = H.call_attention(*args, out_dtype=torch.float32, antiq_scale=H.dev(sc3),
+                         antiq_offset=None if of3 is None else H.dev(of3), antiquant_mode=3, **pre_kw)
+    assert torch.equal(a, b)
