@@ -896,8 +896,8 @@ static aclnnStatus plan_lds(spfa::AttnParams& p) {
     const bool per_head = (p.mode == 0 && p.pos_rows == p.Hq && p.G > 1);
     // pseShift / attenMask / per-token antiquant parameters index the columns of ONE head's list: every q head runs
     // as its own pass
-    int nq = (per_head || p.pse || p.amask || p.token_mode || p.antiq_per_token) ? 1
-                                                                                  : spfa::attention_rows_per_pass(p.G, p.kv_dtype, p.D);
+    // (token-level lists: a list per kv head is streamed once for the whole group; a list per q head is a pass of its own)
+    int nq = (per_head || p.pse || p.amask || p.antiq_per_token) ? 1 : spfa::attention_rows_per_pass(p.G, p.kv_dtype, p.D);
     size_t need = carve_lds(p, (size_t)nq);
     // a large group with many clusters: fewer q heads per pass (more passes over the pages) until the keys fit
     while (need > kMaxLds && nq > 2 && spfa::attention_uses_mfma(nq, p.kv_dtype, p.D)) {

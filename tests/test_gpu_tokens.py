@@ -62,6 +62,14 @@ def _random_lists(rng, B, rows, max_tokens, seq_tokens, counts):
     (3, 8, 4, 128, 128, "i8", "BSH", False, 640),
     (2, 4, 4, 64, 32, "i8", "BNSD", True, 200),
     (40, 32, 32, 128, 128, "f16", "BSH", True, 384),      # 1280 items: more than the resident workgroups
+    # lists shared by a group are streamed once for all its q heads (the matrix-core streamer, token-addressed)
+    (3, 32, 4, 128, 128, "f16", "BSH", False, 700),      # groups of 8
+    (3, 16, 4, 128, 128, "bf16", "BNSD", False, 500),
+    (3, 8, 2, 64, 16, "f16", "BSH", False, 260),
+    (2, 16, 4, 64, 32, "i8", "BNSD", False, 333),
+    (2, 64, 2, 128, 128, "f16", "BSH", False, 450),      # groups of 32: two passes of 16 heads
+    (1, 32, 8, 128, 128, "f16", "BSH", False, 1400),     # one sequence: the list is dealt to several workgroups
+    (80, 32, 8, 128, 128, "i8", "BSH", False, 300),      # 640 items: more than the resident workgroups
 ])
 def test_token_lists_vs_oracle(H, B, Hq, Hkv, D, bs, kvdt, layout, rows_hq, max_tokens):
     rng = datagen.rng_for(7 * B + Hq + max_tokens)
