@@ -131,13 +131,13 @@ bool attention_uses_mfma(int rows_per_pass, int kv_dtype, int D) {
 }
 
 int attention_stream_waves(bool mfma, int kv_dtype, bool narrow) { return stream_waves(mfma, kv_dtype == kI8, narrow); }
-int attention_score_waves(bool mfma, int kv_dtype, int D, bool narrow) {
-    const int all = stream_waves(mfma, kv_dtype == kI8, narrow) + sel_waves(mfma);
+int attention_score_waves(bool mfma, int kv_dtype, int D, bool narrow, bool sup) {
+    const int all = stream_waves(mfma, kv_dtype == kI8, narrow) + sel_waves(mfma, sup, narrow);
     if (mfma) return all;   // the streamers lend their V tile areas
     return D <= 128 ? all : (all < 5 ? all : 5);   // 8 / 16 KiB tiles: five of them, as much as nine 4 KiB ones
 }
-int attention_stage_bytes(bool mfma, int kv_dtype, int D, bool narrow) {
-    return (mfma ? sel_waves(true) : attention_score_waves(false, kv_dtype, D, narrow)) * score_stage_bytes(D);
+int attention_stage_bytes(bool mfma, int kv_dtype, int D, bool narrow, bool sup) {
+    return (mfma ? sel_waves(true) : attention_score_waves(false, kv_dtype, D, narrow, sup)) * score_stage_bytes(D);
 }
 // 4 KiB tiles (D <= 128): every wave; 8 / 16 KiB tiles: four / two waves, the same 33 KiB
 int cent_score_waves(int D) { return D <= 128 ? kCentWaves : (D <= 256 ? 4 : 2); }
