@@ -857,6 +857,7 @@ static aclnnStatus plan_oneshot_extras(spfa::AttnParams& p, const AttentionExtra
     return ACLNN_SUCCESS;
 }
 
+constexpr int kTokenWindow = 4096;       // most entries of a token-level list held in LDS at a time (per pipeline slot)
 constexpr uint64_t kCounterBytes = 256;   // 8 work counters at the start of the workspace, zeroed per launch
 
 static size_t carve_lds(spfa::AttnParams& p, size_t nq) {
@@ -882,6 +883,9 @@ static size_t carve_lds(spfa::AttnParams& p, size_t nq) {
     off += align16((size_t)2 * sw * nq * (p.D + 2) * 4);                   // streamer states of two items
     p.off_qst = (int)off;
     if (!mfma) off += align16((size_t)2 * nq * p.D * 4);                   // pre-scaled q rows (VALU streamer)
+    p.off_carry = (int)off;
+    if (p.token_mode && p.max_entries < round_up(p.P, p.block_size))       // the list is streamed in windows
+        off += align16((size_t)2 * nq * (p.D + 2) * 4);
     p.off_hdr = (int)off;
     off += 2 * 48 + 16 + 64 + 144;                                         // two item headers + 4 workgroup words + 16 pipeline words + chunk table
     p.off_vst = (int)off;
@@ -899,6 +903,22 @@ static aclnnStatus plan_lds(spfa::AttnParams& p) {
     // (token-level lists: a list per kv head is streamed once for the whole group; a list per q head is a pass of its own)
     int nq = (per_head || p.pse || p.amask || p.antiq_per_token) ? 1 : spfa::attention_rows_per_pass(p.G, p.kv_dtype, p.D);
     size_t need = carve_lds(p, (size_t)nq);
+    if (p.token_mode) {
+        // Token-level lists: the whole list when it has at most kTokenWindow entries, else windows of that size (a window
+        // boundary costs every streamer wave a drained load pipeline and a reload of its q rows: measured 2.5 % per
+        // boundary on 100 us items); smaller windows before fewer q heads per pass where the areas of a wide pass leave
+        // less room.
+        const int whole = round_up(p.P, p.block_size);
+        const char* forced = getenv("SPFA_TOKEN_WINDOW");   // tests and experiments: the largest window
+        const int w_max = forced && atoi(forced) > 0 ? atoi(forced) : kTokenWindow;
+        int w = std::min(whole, std::max(p.block_size, w_max / p.block_size * p.block_size));
+        for (;;) {
+            p.max_entries = w;
+            need = carve_lds(p, (size_t)nq);
+            if (need <= kMaxLds || w <= std::max(p.block_size, 512)) break;
+            w = std::max(p.block_size, w / 2 / p.block_size * p.block_size);
+        }
+    }
     // a large group with many clusters: fewer q heads per pass (more passes over the pages) until the keys fit
     while (need > kMaxLds && nq > 2 && spfa::attention_uses_mfma(nq, p.kv_dtype, p.D)) {
         nq = (nq + 1) / 2;
@@ -1268,6 +1288,8 @@ aclnnStatus aclnnSparsePagedAttentionGetWorkspaceSize(
         if (!absent(pseShift) || !absent(attenMask))
             return bail(fail(ACLNN_ERR_PARAM_INVALID, "pseShift / attenMask are not supported with token-level positions"));
         p.token_mode = 1;
+        // the LDS area holds a window of the list (whole virtual pages); longer lists are streamed window by window
+        // (plan_lds settles the window)
         p.max_entries = round_up(p.P, p.block_size);
     }
     p.act_seq_uniform = -1;

@@ -201,6 +201,7 @@ struct AttnParams {
     int score_waves;
     // LDS carve (bytes from the dynamic base)
     int off_keys, off_cbits, off_pbits, off_list, off_comb, off_qst, off_hdr, off_vst, off_stage;
+    int off_carry;            // token-level lists streamed in windows: two merged states [rows_per_pass][D + 2]
     size_t lds_bytes;
 };
 

@@ -72,8 +72,31 @@ def _random_lists(rng, B, rows, max_tokens, seq_tokens, counts):
     (80, 32, 8, 128, 128, "i8", "BSH", False, 300),      # 640 items: more than the resident workgroups
 ])
 def test_token_lists_vs_oracle(H, B, Hq, Hkv, D, bs, kvdt, layout, rows_hq, max_tokens):
+    _run_case(H, B, Hq, Hkv, D, bs, kvdt, layout, rows_hq, max_tokens, 12)
+
+
+@pytest.mark.parametrize("B,Hq,Hkv,D,bs,kvdt,layout,rows_hq,max_tokens,max_page", [
+    (2, 8, 8, 128, 128, "f16", "BSH", True, 5000, 48),       # three windows, one q head per pass
+    (2, 8, 2, 128, 128, "f16", "BSH", False, 10000, 100),    # group form, five windows
+    (2, 16, 4, 128, 128, "i8", "BSH", False, 9000, 80),
+    (1, 8, 8, 64, 16, "bf16", "BNSD", True, 2500, 200),      # one sequence: windows of a list dealt to several workgroups
+    (1, 32, 8, 128, 128, "f16", "BSH", False, 6000, 50),
+    (24, 32, 32, 128, 128, "f16", "BSH", True, 2300, 24),    # 768 items, two windows each, through the queue
+])
+@pytest.mark.parametrize("window", [None, 512])
+def test_long_token_lists_are_streamed_in_windows(H, monkeypatch, B, Hq, Hkv, D, bs, kvdt, layout, rows_hq, max_tokens,
+                                                  max_page, window):
+    """The workgroup holds at most 4096 entries of a list at a time (fewer where a wide pass leaves less room; 512 when
+    the test asks for it); longer lists go through as windows whose states are merged.  Rows of exactly one and two
+    windows, a row that ends one entry into a window, and random lengths."""
+    if window:
+        monkeypatch.setenv("SPFA_TOKEN_WINDOW", str(window))
+    w = window or 4096
+    _run_case(H, B, Hq, Hkv, D, bs, kvdt, layout, rows_hq, max_tokens, max_page, exact=(w, 2 * w, w + 1))
+
+
+def _run_case(H, B, Hq, Hkv, D, bs, kvdt, layout, rows_hq, max_tokens, max_page, exact=()):
     rng = datagen.rng_for(7 * B + Hq + max_tokens)
-    max_page = 12
     n_blocks = min(B * max_page, 160)
     k, v, sc, off = _pool(11, n_blocks, bs, Hkv, D, layout, kvdt)
     table = rng.integers(0, n_blocks, size=(B, max_page)).astype(np.int32)
@@ -82,6 +105,10 @@ def test_token_lists_vs_oracle(H, B, Hq, Hkv, D, bs, kvdt, layout, rows_hq, max_
     counts = [[int(rng.integers(1, min(max_tokens, seq_tokens[b]) + 1)) for _ in range(rows)] for b in range(B)]
     counts[0][0] = min(max_tokens, seq_tokens[0])                         # a full row (no sentinel)
     counts[B - 1][rows - 1] = 1                                           # a single token
+    for i, n in enumerate(exact):
+        b, r = (i + 1) % B, (i + 1) % rows
+        if n <= min(max_tokens, seq_tokens[b]) and (b, r) not in ((0, 0), (B - 1, rows - 1)):
+            counts[b][r] = n
     tp = _random_lists(rng, B, rows, max_tokens, seq_tokens, counts)
     q = datagen.ref_rand_f16(rng, (B, Hq, D)).astype(np.float32)
     if kvdt == "bf16":
