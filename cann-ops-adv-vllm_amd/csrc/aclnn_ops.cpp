@@ -867,12 +867,13 @@ static size_t carve_lds(spfa::AttnParams& p, size_t nq) {
     // one being prepared)
     const size_t sel_rows = p.sup_items > 1 ? (size_t)p.sup_items : nq * (size_t)(p.pre_items > 1 ? p.pre_items : 1);
     const size_t bit_rows = p.sup_items > 1 ? 2 * (size_t)p.sup_items : sel_rows;
+    const bool team = spfa::attention_team(p);   // a team of four selector waves: a cluster bitmap each
     p.off_keys = (int)off;
     if (p.mode == 1) off += align16(sel_rows * p.Cp * 4);                  // score keys (selector wave)
     p.off_cbits = (int)off;
     const size_t max_waves = 16;   // upper bound of the waves of a workgroup (streamers + selectors)
     if (p.mode == 1)   // top-k cluster bitmaps (one per wave that selects a row of the first item) + 16 row lengths
-        off += align16((sel_rows < max_waves ? (p.sup_items > 1 && sel_rows < 4 ? 4 : sel_rows) : max_waves) * (size_t)(p.Cp / 32) * 4) + 64;
+        off += align16((sel_rows < max_waves ? (team && sel_rows < 4 ? 4 : sel_rows) : max_waves) * (size_t)(p.Cp / 32) * 4) + 64;
     p.off_pbits = (int)off;
     if (p.mode == 1) off += align16(bit_rows * ((p.max_page + 63) / 64) * 8);   // per-head page bitmaps
     p.off_list = (int)off;
@@ -891,8 +892,8 @@ static size_t carve_lds(spfa::AttnParams& p, size_t nq) {
     p.off_vst = (int)off;
     if (mfma) off += sw * 32 * (p.D * 2 + 32);                             // V tile images of the streamer waves
     p.off_stage = (int)off;
-    if (p.mode == 1) off += (size_t)spfa::attention_stage_bytes(mfma, p.kv_dtype, p.D, p.narrow != 0, p.sup_items > 1);   // centroid tiles of the scoring waves
-    p.score_waves = spfa::attention_score_waves(mfma, p.kv_dtype, p.D, p.narrow != 0, p.sup_items > 1);
+    if (p.mode == 1) off += (size_t)spfa::attention_stage_bytes(mfma, p.kv_dtype, p.D, p.narrow != 0, team);   // centroid tiles of the scoring waves
+    p.score_waves = spfa::attention_score_waves(mfma, p.kv_dtype, p.D, p.narrow != 0, team);
     return off;
 }
 

@@ -130,6 +130,9 @@ bool attention_uses_mfma(int rows_per_pass, int kv_dtype, int D) {
     return rows_per_pass > 1 && D <= 256;
 }
 
+bool attention_team(const AttnParams& p) {
+    return p.sup_items > 1 || (SPFA_TEAM_ALL && p.rows_per_pass == 1 && !p.token_mode && !p.antiq_per_token && !p.narrow);
+}
 int attention_stream_waves(bool mfma, int kv_dtype, bool narrow) { return stream_waves(mfma, kv_dtype == kI8, narrow); }
 int attention_score_waves(bool mfma, int kv_dtype, int D, bool narrow, bool sup) {
     const int all = stream_waves(mfma, kv_dtype == kI8, narrow) + sel_waves(mfma, sup, narrow);

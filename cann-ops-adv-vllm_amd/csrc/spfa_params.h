@@ -245,7 +245,8 @@ bool attention_uses_mfma(int rows_per_pass, int kv_dtype, int D);
 int attention_stream_waves(bool mfma, int kv_dtype, bool narrow);
 // LDS tiles through which the centroid pass turns memory order into matrix-core operand order: bytes at off_stage of
 // the attention kernels, and at the end of the dynamic LDS of the cent kernels.
-// sup: a plan with batched selection (a team of selector waves in the wide workgroup)
+bool attention_team(const AttnParams& p);   // the plan's kernel runs a team of selector waves
+// sup: such a plan
 int attention_stage_bytes(bool mfma, int kv_dtype, int D, bool narrow, bool sup);
 int attention_score_waves(bool mfma, int kv_dtype, int D, bool narrow, bool sup);   // AttnParams::score_waves of a plan
 int cent_score_waves(int D);     // waves that share the pass of the standalone scoring kernels

@@ -1,7 +1,7 @@
 #!/bin/bash
-# Evidence of round 3 (run on the GPU box from the repository root): everything lands in gpurun_out/prof_r03/ as small
+# Measurement evidence (run on the GPU box from the repository root): everything lands in gpurun_out/prof_r03/ as small
 # summaries, to be copied into profiles/.  Parts: bench lines (c3 with the drop-in leg, c4, c5, rehearsals of the ranks),
-# rocprofv3 kernel stats of every launch shape quoted in DESIGN.md, HBM traffic counters (FETCH_SIZE and WRITE_SIZE in
+# rocprofv3 kernel stats of every launch shape the design notes quote, HBM traffic counters (FETCH_SIZE and WRITE_SIZE in
 # separate passes) for c3 / c4 / c5, matrix-core counters of the MFMA-form attention kernel and of the scoring kernels,
 # the SQ / TCP / TCC comparison of c3 and c4, the compiled caller's repeated launch.
 tag=r03
@@ -24,6 +24,8 @@ timeout -k 10 300 python3 bench.py --workload c5 --batch 8 --no-cpu-baseline --n
 bash tools/shapes_check.sh > $out/shapes.log 2>&1
 TOKEN_ROWS=kv timeout -k 10 200 python3 tools/token_bench.py --kv-heads 8 > $out/token_bench_gqa.log 2>&1
 timeout -k 10 200 python3 tools/token_bench.py > $out/token_bench_mha.log 2>&1
+TOKEN_ROWS=kv timeout -k 10 200 python3 tools/token_bench.py --kv-heads 8 --kv int8 --seqlen 65536 > $out/token_bench_gqa_int8_s64k.log 2>&1
+TOKEN_ROWS=kv timeout -k 10 200 python3 tools/token_bench.py --kv-heads 8 --seqlen 131072 > $out/token_bench_gqa_s128k.log 2>&1
 timeout -k 10 120 python3 tools/cent_only.py > $out/cent_only.log 2>&1
 
 cd /tmp && export TMPDIR=/tmp
