@@ -135,7 +135,8 @@ SPFA_API aclnnStatus spfaSetActualSeqLengthsDevice(const int64_t* deviceLengths,
  * numKeyValueHeads, maxTokens] as LOGICAL TOKEN indices instead of page indices (token t = row t % blockSize of page
  * blocktable[b][t / blockSize]; a row ends at its first 0x7fffffff) and actualSeqLengths as token counts — the
  * token-level variant the reference sketches in tests/ifa_v5_case_tkp.py:53-54.  Head dims 64 and 128; pseShift /
- * attenMask are refused; every q head is streamed as its own pass. */
+ * attenMask are refused; any maxTokens (lists above 4096 entries are streamed in windows).  With numHeads rows every q
+ * head is a pass of its own; with numKeyValueHeads rows a list is streamed once for the q heads of its group. */
 SPFA_API aclnnStatus spfaSetTokenPositions(int enable);
 /* One-shot: antiquant mode of the next phase 1 of the two sparse attention ops on this thread — the antiquantMode
  * attribute of the kernel the sparse ops were derived from (sparse_paged_fusion_attention_tiling.cc:719-765,982-984),
