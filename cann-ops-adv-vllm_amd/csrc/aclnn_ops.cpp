@@ -391,10 +391,11 @@ int spfaDescribeExecutor(const aclOpExecutor* e, char* buf, uint64_t n) {
     const bool mfma = spfa::attention_uses_mfma(p.rows_per_pass, p.kv_dtype, p.D);
     const int w = snprintf(buf, n,
                            "form=%s geometry=%s rows_per_pass=%d scored_ahead=%d lists_ahead=%d super_items=%d split=%d "
-                           "tail_sharing=%d resident_workgroups=%lld lds_bytes=%zu workspace_bytes=%llu zeroed_bytes=%llu",
+                           "tail_sharing=%d resident_workgroups=%lld lds_bytes=%zu workspace_bytes=%llu zeroed_bytes=%llu "
+                           "token_window=%d",
                            mfma ? "mfma" : "valu", p.narrow ? "narrow" : "wide", p.rows_per_pass, p.pre_items, p.pre_lists,
                            p.sup_items, p.n_split, p.tail_on, p.grid_cap, p.lds_bytes, (unsigned long long)e->ws_bytes,
-                           (unsigned long long)e->ws_zero_bytes);
+                           (unsigned long long)e->ws_zero_bytes, p.token_mode ? p.max_entries : 0);
     return w < 0 ? -1 : (w < (int)n ? w : (int)n - 1);
 }
 uint64_t spfaKernelLaunches(void) { return spfa::launches_so_far(); }

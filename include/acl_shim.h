@@ -183,7 +183,7 @@ SPFA_API aclnnStatus spfaSetWorkspacePersistent(aclOpExecutor* executor, int ena
 SPFA_API aclnnStatus spfaSetLibraryCounters(int enable);
 /* The launch plan of an executor of the two attention ops as one line of text (kernel form, workgroup geometry, rows per
  * pass, items scored ahead, super-items, page-list split, sharing of last items, resident workgroups, LDS and workspace
- * bytes): for logs and tests.  Returns the number of characters written, -1 on a bad argument. */
+ * bytes, entries of a token-level list held in LDS at a time): for logs and tests.  Returns the number of characters written, -1 on a bad argument. */
 SPFA_API int spfaDescribeExecutor(const aclOpExecutor* executor, char* buf, uint64_t n);
 /* Kernels the library has enqueued (or recorded into a graph) since it was loaded, over all threads and devices: the
  * difference around a call tells how many kernels that call was. */

@@ -310,3 +310,41 @@ def test_one_shot_extras_are_validated_and_consumed(lib):
     for g in (1, 2, 0):
         assert lib.spfaSetWorkgroupGeometry(g) == 0
         assert attention(lib)[0] == 0
+
+
+def test_token_lists_are_planned_in_windows(lib, monkeypatch):
+    """Token-level positions of any length: the plan holds the whole list in LDS up to 4096 entries, a window of 4096
+    beyond that, and a smaller window where a 16-head pass leaves less room."""
+    lib.spfaSetTokenPositions.argtypes = [c_int]
+    lib.spfaDescribeExecutor.argtypes = [c_void_p, c_char_p, c_uint64]
+
+    def window(P, Hq=8, Hkv=2, bs=128, kv_dtype=F16, antiq=None):
+        B, D = 2, 128
+        q = tensor(lib, (B, Hq, D), F16)
+        kv = (40, bs, Hkv, D)
+        k, v = tlist(lib, tensor(lib, kv, kv_dtype)), tlist(lib, tensor(lib, kv, kv_dtype))
+        table, pos = tensor(lib, (B, 400), I32), tensor(lib, (B, Hkv, P), I32)
+        out = tensor(lib, (B, Hq, D), F16)
+        ws, ex = c_uint64(0), c_void_p()
+        assert lib.spfaSetTokenPositions(1) == 0
+        st = lib.aclnnSparsePagedAttentionGetWorkspaceSize(q, k, v, None, None, None, None, None, None, None, None, antiq,
+                                                           None, table, None, pos, Hq, 0.088, b"BNSD", Hkv, bs, 1, out,
+                                                           ctypes.byref(ws), ctypes.byref(ex))
+        assert st == 0, lib.aclGetRecentErrMsg()
+        buf = ctypes.create_string_buffer(512)
+        assert lib.spfaDescribeExecutor(ex, buf, 512) > 0
+        lib.aclDestroyAclOpExecutor(ex)
+        plan = dict(part.split("=") for part in buf.value.decode().split())
+        return int(plan["token_window"]), int(plan["rows_per_pass"]), int(plan["lds_bytes"])
+
+    assert window(700)[0] == 768                      # whole list, padded to virtual pages of 128 entries
+    assert window(4096)[0] == 4096
+    assert window(4097)[0] == 4096                    # two windows
+    assert window(50000)[0] == 4096
+    assert window(50000, bs=48)[0] == 4080            # whole virtual pages
+    w, rows, lds = window(50000, Hq=32, Hkv=2)        # 16 q heads per pass: wider state areas, smaller window, same rows
+    assert rows == 16 and w < 4096 and w % 128 == 0 and lds <= 160 * 1024
+    w, rows, lds = window(20000, Hq=16, Hkv=4, kv_dtype=I8, antiq=tensor(lib, (2, 4, 128), F16))
+    assert rows == 4 and w == 4096 and lds <= 160 * 1024
+    monkeypatch.setenv("SPFA_TOKEN_WINDOW", "512")
+    assert window(50000)[0] == 512 and window(300)[0] == 384
