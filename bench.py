@@ -419,6 +419,8 @@ def main():
         _abi.spfaSetWorkgroupGeometry(int(os.environ["SPFA_GEOM"]))
     if os.environ.get("SPFA_BATCHED_SELECTION"):
         _abi.spfaSetBatchedSelection(int(os.environ["SPFA_BATCHED_SELECTION"]))
+    if os.environ.get("SPFA_K_THROUGH_LDS"):
+        _abi.spfaSetKThroughLds(int(os.environ["SPFA_K_THROUGH_LDS"]))
     if a.no_tail_sharing:
         _abi.spfaSetTailSharing(0)
     if a.force_tail_sharing:
@@ -437,6 +439,8 @@ def main():
                                          antiquant_offset=wl["a_off"], k=a.topk)
 
     plan = make_plan(pos, plen, pmax)
+    if os.environ.get("SPFA_DESCRIBE") and rank == 0:
+        print("[bench] plan:", plan.describe(), file=sys.stderr)
     reducer = shard.GlobalMaxLength(device, every=a.allreduce_every,
                                     depth=int(os.environ.get("BENCH_REDUCER_DEPTH", "4"))) if dist is not None else None
     # With a collective behind every launch the decode loop alternates two sets of output tensors (as a serving loop

@@ -66,6 +66,7 @@ thread_local int g_tail_sharing = 1;
 thread_local int g_shared_scoring = 1;
 thread_local int g_stream_slots = 1;       // 1: launches may keep their counters in library-owned per-stream slots
 thread_local int g_super_items = 1;        // 1: the planner may batch the selection of queue-fed launches (super-items)
+thread_local int g_k_through_lds = 1;      // 1: the matrix-core streamer takes K through LDS where the image fits
 thread_local int g_geometry = 0;           // 0: planner's choice, 1: wide, 2: narrow workgroups of the one-q-head kernels
 thread_local int64_t g_page_size = 128;   // PAGESIZE of cent_select.cpp:17 / select_position.cpp:112
 thread_local const long long* g_act_seq_dev = nullptr;   // one-shot, consumed by the next attention plan
@@ -339,6 +340,7 @@ aclnnStatus spfaSetWorkgroupGeometry(int geometry) {
     return ACLNN_SUCCESS;
 }
 aclnnStatus spfaSetBatchedSelection(int enable) { g_super_items = enable ? 1 : 0; return ACLNN_SUCCESS; }
+aclnnStatus spfaSetKThroughLds(int enable) { g_k_through_lds = enable ? 1 : 0; return ACLNN_SUCCESS; }
 aclnnStatus spfaSetLibraryCounters(int enable) { g_stream_slots = enable ? 1 : 0; return ACLNN_SUCCESS; }
 aclnnStatus spfaSetPageSize(int64_t page_size) {
     if (page_size < 1 || page_size > 512) return fail(ACLNN_ERR_PARAM_INVALID, "page size %lld out of [1, 512]", (long long)page_size);
@@ -392,10 +394,10 @@ int spfaDescribeExecutor(const aclOpExecutor* e, char* buf, uint64_t n) {
     const int w = snprintf(buf, n,
                            "form=%s geometry=%s rows_per_pass=%d scored_ahead=%d lists_ahead=%d super_items=%d split=%d "
                            "tail_sharing=%d resident_workgroups=%lld lds_bytes=%zu workspace_bytes=%llu zeroed_bytes=%llu "
-                           "token_window=%d",
+                           "token_window=%d k_through_lds=%d",
                            mfma ? "mfma" : "valu", p.narrow ? "narrow" : "wide", p.rows_per_pass, p.pre_items, p.pre_lists,
                            p.sup_items, p.n_split, p.tail_on, p.grid_cap, p.lds_bytes, (unsigned long long)e->ws_bytes,
-                           (unsigned long long)e->ws_zero_bytes, p.token_mode ? p.max_entries : 0);
+                           (unsigned long long)e->ws_zero_bytes, p.token_mode ? p.max_entries : 0, mfma ? p.k_lds : 0);
     return w < 0 ? -1 : (w < (int)n ? w : (int)n - 1);
 }
 uint64_t spfaKernelLaunches(void) { return spfa::launches_so_far(); }
@@ -891,7 +893,8 @@ static size_t carve_lds(spfa::AttnParams& p, size_t nq) {
     p.off_hdr = (int)off;
     off += 2 * 48 + 16 + 64 + 144;                                         // two item headers + 4 workgroup words + 16 pipeline words + chunk table
     p.off_vst = (int)off;
-    if (mfma) off += sw * 32 * (p.D * 2 + 32);                             // V tile images of the streamer waves
+    p.vst_stride = spfa::mfma_tile_area(p.D, p.kv_dtype == spfa::kI8 ? 1 : 2, mfma && p.k_lds);
+    if (mfma) off += sw * (size_t)p.vst_stride;                           // V (and K) tile images of the streamer waves
     p.off_stage = (int)off;
     if (p.mode == 1) off += (size_t)spfa::attention_stage_bytes(mfma, p.kv_dtype, p.D, p.narrow != 0, team);   // centroid tiles of the scoring waves
     p.score_waves = spfa::attention_score_waves(mfma, p.kv_dtype, p.D, p.narrow != 0, team);
@@ -904,12 +907,14 @@ static aclnnStatus plan_lds(spfa::AttnParams& p) {
     // as its own pass
     // (token-level lists: a list per kv head is streamed once for the whole group; a list per q head is a pass of its own)
     int nq = (per_head || p.pse || p.amask || p.antiq_per_token) ? 1 : spfa::attention_rows_per_pass(p.G, p.kv_dtype, p.D);
-    size_t need = carve_lds(p, (size_t)nq);
-    if (p.token_mode) {
-        // Token-level lists: the whole list when it has at most kTokenWindow entries, else windows of that size (a window
-        // boundary costs every streamer wave a drained load pipeline and a reload of its q rows: measured 2.5 % per
-        // boundary on 100 us items); smaller windows before fewer q heads per pass where the areas of a wide pass leave
-        // less room.
+    // Token-level lists: the whole list when it has at most kTokenWindow entries, else windows of that size (a window
+    // boundary costs every streamer wave a drained load pipeline and a reload of its q rows: measured 2.5 % per boundary
+    // on 100 us items); smaller windows before fewer q heads per pass where the areas of a wide pass leave less room.
+    size_t need = 0;
+    auto fit = [&](int k_lds) {
+        p.k_lds = k_lds;
+        need = carve_lds(p, (size_t)nq);
+        if (!p.token_mode) return;
         const int whole = round_up(p.P, p.block_size);
         const char* forced = getenv("SPFA_TOKEN_WINDOW");   // tests and experiments: the largest window
         const int w_max = forced && atoi(forced) > 0 ? atoi(forced) : kTokenWindow;
@@ -920,6 +925,14 @@ static aclnnStatus plan_lds(spfa::AttnParams& p) {
             if (need <= kMaxLds || w <= std::max(p.block_size, 512)) break;
             w = std::max(p.block_size, w / 2 / p.block_size * p.block_size);
         }
+    };
+    // The matrix-core streamer takes K through LDS (head dims up to 128) where the images fit beside everything else:
+    // never at the price of fewer q heads per pass or of a smaller window of a token-level list.
+    fit(0);
+    if (g_k_through_lds && p.D <= 128 && spfa::attention_uses_mfma(nq, p.kv_dtype, p.D) && need <= kMaxLds) {
+        const int window = p.max_entries;
+        fit(1);
+        if (need > kMaxLds || p.max_entries != window) fit(0);
     }
     // a large group with many clusters: fewer q heads per pass (more passes over the pages) until the keys fit
     while (need > kMaxLds && nq > 2 && spfa::attention_uses_mfma(nq, p.kv_dtype, p.D)) {

@@ -202,6 +202,9 @@ struct AttnParams {
     // LDS carve (bytes from the dynamic base)
     int off_keys, off_cbits, off_pbits, off_list, off_comb, off_qst, off_hdr, off_vst, off_stage;
     int off_carry;            // token-level lists streamed in windows: two merged states [rows_per_pass][D + 2]
+    int k_lds;                // matrix-core streamer: K is fetched in whole rows (every request a full cache line) and
+                              // turned into operand order through a wave-private LDS image, as V is
+    int vst_stride;           // bytes of tile images per streamer wave at off_vst
     size_t lds_bytes;
 };
 
@@ -245,6 +248,11 @@ bool attention_uses_mfma(int rows_per_pass, int kv_dtype, int D);
 int attention_stream_waves(bool mfma, int kv_dtype, bool narrow);
 // LDS tiles through which the centroid pass turns memory order into matrix-core operand order: bytes at off_stage of
 // the attention kernels, and at the end of the dynamic LDS of the cent kernels.
+// bytes of LDS per streamer wave of the matrix-core form: the V image of a 32-token tile (16-bit elements, rows padded by
+// 32 B) and, with k_lds, the K image behind it (elements as stored, rows padded by 16 B)
+constexpr int mfma_tile_area(int D, int kv_elem_bytes, bool k_lds) {
+    return 32 * (D * 2 + 32) + (k_lds ? 32 * (D * kv_elem_bytes + 16) : 0);
+}
 bool attention_team(const AttnParams& p);   // the plan's kernel runs a team of selector waves
 // sup: such a plan
 int attention_stage_bytes(bool mfma, int kv_dtype, int D, bool narrow, bool sup);

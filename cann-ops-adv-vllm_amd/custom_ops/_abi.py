@@ -66,6 +66,7 @@ spfaSetSoftmaxLseOut = _sig("spfaSetSoftmaxLseOut", c_int, [c_void_p, c_int64])
 spfaSetSharedPrefix = _sig("spfaSetSharedPrefix", c_int, [c_void_p, c_void_p, c_int64, c_int64])
 spfaSetWorkspacePersistent = _sig("spfaSetWorkspacePersistent", c_int, [T, c_int])
 spfaSetBatchedSelection = _sig("spfaSetBatchedSelection", c_int, [c_int])
+spfaSetKThroughLds = _sig("spfaSetKThroughLds", c_int, [c_int])
 spfaSetLibraryCounters = _sig("spfaSetLibraryCounters", c_int, [c_int])
 spfaDescribeExecutor = _sig("spfaDescribeExecutor", c_int, [T, ctypes.c_char_p, c_uint64])
 spfaKernelLaunches = _sig("spfaKernelLaunches", c_uint64, [])
