@@ -23,18 +23,24 @@ TOL = 1e-3
 
 class _Knobs:
     """Launch-planning knobs for one test: tail sharing forced on / off, page-list split off, the workgroup geometry of the
-    one-q-head kernels forced wide / narrow (all restored)."""
+    one-q-head kernels forced wide / narrow, strided K loads in the group passes, a 256-entry window for token-level
+    lists (all restored)."""
 
     def __init__(self, seed):
         self.tail = {3: 2, 6: 0}.get(seed % 8, 1)
         self.split = 1 if seed % 8 == 5 else (3 if seed % 8 == 1 else 16)
         self.geometry = {0: 1, 1: 2, 2: 2}.get(seed % 5, 0)
+        self.k_lds = 0 if seed % 3 == 1 else 1
+        self.window = "256" if seed % 4 == 2 else None
 
     def __enter__(self):
         from custom_ops import _abi
         _abi.check(_abi.spfaSetTailSharing(self.tail), "spfaSetTailSharing")
         _abi.check(_abi.spfaSetMaxSplit(self.split), "spfaSetMaxSplit")
         _abi.check(_abi.spfaSetWorkgroupGeometry(self.geometry), "spfaSetWorkgroupGeometry")
+        _abi.check(_abi.spfaSetKThroughLds(self.k_lds), "spfaSetKThroughLds")
+        if self.window:
+            os.environ["SPFA_TOKEN_WINDOW"] = self.window
         return self
 
     def __exit__(self, *exc):
@@ -42,6 +48,8 @@ class _Knobs:
         _abi.spfaSetTailSharing(1)
         _abi.spfaSetMaxSplit(16)
         _abi.spfaSetWorkgroupGeometry(0)
+        _abi.spfaSetKThroughLds(1)
+        os.environ.pop("SPFA_TOKEN_WINDOW", None)
         return False
 
 
