@@ -893,7 +893,7 @@ static size_t carve_lds(spfa::AttnParams& p, size_t nq) {
     p.off_hdr = (int)off;
     off += 2 * 48 + 16 + 64 + 144;                                         // two item headers + 4 workgroup words + 16 pipeline words + chunk table
     p.off_vst = (int)off;
-    p.vst_stride = spfa::mfma_tile_area(p.D, p.kv_dtype == spfa::kI8 ? 1 : 2, mfma && p.k_lds);
+    p.vst_stride = spfa::mfma_tile_area(p.D);
     if (mfma) off += sw * (size_t)p.vst_stride;                           // V (and K) tile images of the streamer waves
     p.off_stage = (int)off;
     if (p.mode == 1) off += (size_t)spfa::attention_stage_bytes(mfma, p.kv_dtype, p.D, p.narrow != 0, team);   // centroid tiles of the scoring waves
@@ -910,11 +910,11 @@ static aclnnStatus plan_lds(spfa::AttnParams& p) {
     // Token-level lists: the whole list when it has at most kTokenWindow entries, else windows of that size (a window
     // boundary costs every streamer wave a drained load pipeline and a reload of its q rows: measured 2.5 % per boundary
     // on 100 us items); smaller windows before fewer q heads per pass where the areas of a wide pass leave less room.
-    size_t need = 0;
-    auto fit = [&](int k_lds) {
-        p.k_lds = k_lds;
-        need = carve_lds(p, (size_t)nq);
-        if (!p.token_mode) return;
+    // The matrix-core streamer takes K through LDS for head dims up to 128 (the K image of a tile lies in the bytes of its
+    // V image: no LDS of its own).
+    p.k_lds = (g_k_through_lds && p.D <= 128) ? 1 : 0;
+    size_t need = carve_lds(p, (size_t)nq);
+    if (p.token_mode) {
         const int whole = round_up(p.P, p.block_size);
         const char* forced = getenv("SPFA_TOKEN_WINDOW");   // tests and experiments: the largest window
         const int w_max = forced && atoi(forced) > 0 ? atoi(forced) : kTokenWindow;
@@ -925,14 +925,6 @@ static aclnnStatus plan_lds(spfa::AttnParams& p) {
             if (need <= kMaxLds || w <= std::max(p.block_size, 512)) break;
             w = std::max(p.block_size, w / 2 / p.block_size * p.block_size);
         }
-    };
-    // The matrix-core streamer takes K through LDS (head dims up to 128) where the images fit beside everything else:
-    // never at the price of fewer q heads per pass or of a smaller window of a token-level list.
-    fit(0);
-    if (g_k_through_lds && p.D <= 128 && spfa::attention_uses_mfma(nq, p.kv_dtype, p.D) && need <= kMaxLds) {
-        const int window = p.max_entries;
-        fit(1);
-        if (need > kMaxLds || p.max_entries != window) fit(0);
     }
     // a large group with many clusters: fewer q heads per pass (more passes over the pages) until the keys fit
     while (need > kMaxLds && nq > 2 && spfa::attention_uses_mfma(nq, p.kv_dtype, p.D)) {

@@ -249,10 +249,9 @@ int attention_stream_waves(bool mfma, int kv_dtype, bool narrow);
 // LDS tiles through which the centroid pass turns memory order into matrix-core operand order: bytes at off_stage of
 // the attention kernels, and at the end of the dynamic LDS of the cent kernels.
 // bytes of LDS per streamer wave of the matrix-core form: the V image of a 32-token tile (16-bit elements, rows padded by
-// 32 B) and, with k_lds, the K image behind it (elements as stored, rows padded by 16 B)
-constexpr int mfma_tile_area(int D, int kv_elem_bytes, bool k_lds) {
-    return 32 * (D * 2 + 32) + (k_lds ? 32 * (D * kv_elem_bytes + 16) : 0);
-}
+// 32 B).  With k_lds the K image of the tile (elements as stored, rows padded by 16 B: never larger) lies in the same
+// bytes: a wave has read its K operands back before it writes the V rows, and LDS executes a wave's operations in order.
+constexpr int mfma_tile_area(int D) { return 32 * (D * 2 + 32); }
 bool attention_team(const AttnParams& p);   // the plan's kernel runs a team of selector waves
 // sup: such a plan
 int attention_stage_bytes(bool mfma, int kv_dtype, int D, bool narrow, bool sup);
