@@ -124,11 +124,11 @@ SPFA_API aclnnStatus spfaSetWorkgroupGeometry(int geometry);
  * stream of the group before (one pass per item otherwise).  Outputs do not depend on the setting.  0 turns it off.
  * Default on.  Stays until changed. */
 SPFA_API aclnnStatus spfaSetBatchedSelection(int enable);
-/* Group passes (several q heads share the K / V rows, matrix-core streamer): K rows are fetched whole — every request a
- * full cache line — and turned into matrix operand order through a wave-private LDS image, as V rows are; the planner
- * falls back to strided K loads straight into operand order where the image does not fit LDS.  Outputs do not depend on
- * the setting beyond nothing at all (the same products in the same order).  0 turns it off.  Default on.  Stays until
- * changed. */
+/* Group passes (several q heads share the K / V rows, matrix-core streamer), head dims up to 128: K rows are fetched
+ * whole — every request a full cache line — and turned into matrix operand order through a wave-private LDS image, as V
+ * rows are (the image lies in the bytes of the tile's V image: no LDS of its own).  0: strided K loads straight into
+ * operand order, as at head dim 256.  Outputs do not depend on the setting (the same products in the same order).
+ * Default on.  Stays until changed. */
 SPFA_API aclnnStatus spfaSetKThroughLds(int enable);
 /* page size of the two ops without a blockSize attribute (CentSelect, SelectPosition); the reference
  * compiles in 128 (cent_select.cpp:17, select_position.cpp:112).  Default 128. */
